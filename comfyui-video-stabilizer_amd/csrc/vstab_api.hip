@@ -1,0 +1,156 @@
+// vstab_api.hip -- context, error reporting and staging helpers of libvstab.so.
+#include "vstab_internal.h"
+#include <cstdarg>
+
+static thread_local char g_err[1024] = "";
+
+void vstab_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ScratchBuf::reserve(size_t need)
+{
+    if (need <= bytes) return 0;
+    size_t want = need + need / 4 + 256;
+    if (ptr) {
+        if (pinned_host) (void)hipHostFree(ptr);
+        else (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    hipError_t e = pinned_host ? hipHostMalloc(&ptr, want, hipHostMallocDefault) : hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+        vstab_set_error("scratch allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        ptr = nullptr;
+        return 1;
+    }
+    bytes = want;
+    return 0;
+}
+
+void ScratchBuf::release()
+{
+    if (ptr) {
+        if (pinned_host) (void)hipHostFree(ptr);
+        else (void)hipFree(ptr);
+    }
+    ptr = nullptr;
+    bytes = 0;
+}
+
+bool vstab_invert3x3(const double* S, double* D)
+{
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+               S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d == 0.0) {
+        for (int i = 0; i < 9; i++) D[i] = 0.0;
+        return false;
+    }
+    d = 1.0 / d;
+    double t[9];
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    for (int i = 0; i < 9; i++) D[i] = t[i];
+    return true;
+}
+
+int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** dev_out)
+{
+    // the pinned buffer may still be the source of an in-flight copy from the previous call
+    VSTAB_HIP(hipEventSynchronize(ctx->ev_params_free));
+    if (ctx->h_params.reserve(bytes)) return 1;
+    if (ctx->d_params.reserve(bytes)) return 1;
+    memcpy(ctx->h_params.ptr, host, bytes);
+    VSTAB_HIP(hipMemcpyAsync(ctx->d_params.ptr, ctx->h_params.ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSTAB_HIP(hipEventRecord(ctx->ev_params_free, ctx->stream));
+    *dev_out = ctx->d_params.ptr;
+    return 0;
+}
+
+extern "C" {
+
+int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
+
+const char* vstab_last_error(void) { return g_err; }
+
+int vstab_create(vstab_ctx** out, int device)
+{
+    VSTAB_REQUIRE(out != nullptr, "vstab_create: out is NULL");
+    int count = 0;
+    VSTAB_HIP(hipGetDeviceCount(&count));
+    VSTAB_REQUIRE(count > 0, "vstab_create: no HIP device visible");
+    if (device < 0) VSTAB_HIP(hipGetDevice(&device));
+    VSTAB_REQUIRE(device < count, "vstab_create: device %d out of range (%d visible)", device, count);
+    VSTAB_HIP(hipSetDevice(device));
+    vstab_ctx* ctx = new vstab_ctx();
+    ctx->device = device;
+    ctx->h_params.pinned_host = true;
+    ctx->h_fit.pinned_host = true;
+    VSTAB_HIP(hipEventCreate(&ctx->ev_start));
+    VSTAB_HIP(hipEventCreate(&ctx->ev_stop));
+    VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_params_free, hipEventDisableTiming));
+    VSTAB_HIP(hipEventRecord(ctx->ev_params_free, nullptr));
+    *out = ctx;
+    return 0;
+}
+
+int vstab_destroy(vstab_ctx* ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->h_params.release();
+    ctx->d_params.release();
+    ctx->d_dis.release();
+    ctx->d_fit.release();
+    ctx->h_fit.release();
+    ctx->d_gray_tmp.release();
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipEventDestroy(ctx->ev_params_free);
+    delete ctx;
+    return 0;
+}
+
+int vstab_set_stream(vstab_ctx* ctx, void* hip_stream)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_set_stream: ctx is NULL");
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return 0;
+}
+
+int vstab_synchronize(vstab_ctx* ctx)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_synchronize: ctx is NULL");
+    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int vstab_set_timing(vstab_ctx* ctx, int enabled)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_set_timing: ctx is NULL");
+    ctx->timing = enabled != 0;
+    return 0;
+}
+
+int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out)
+{
+    VSTAB_REQUIRE(ctx != nullptr && kind != nullptr && ms_out != nullptr, "vstab_last_kernel_ms: NULL argument");
+    auto it = ctx->last_ms.find(kind);
+    VSTAB_REQUIRE(it != ctx->last_ms.end(), "vstab_last_kernel_ms: no timing recorded for '%s'", kind);
+    *ms_out = it->second;
+    return 0;
+}
+
+}  // extern "C"

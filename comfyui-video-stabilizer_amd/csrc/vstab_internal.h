@@ -1,0 +1,75 @@
+// vstab_internal.h -- shared between the translation units of libvstab.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/vstab.h"
+
+void vstab_set_error(const char* fmt, ...);
+
+#define VSTAB_HIP(call)                                                                  \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            vstab_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),       \
+                            __FILE__, __LINE__);                                         \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+#define VSTAB_REQUIRE(cond, ...)                                                         \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            vstab_set_error(__VA_ARGS__);                                                \
+            return 2;                                                                    \
+        }                                                                                \
+    } while (0)
+
+// A grow-only device/pinned-host scratch buffer.
+struct ScratchBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    bool pinned_host = false;
+    int reserve(size_t need);
+    void release();
+};
+
+struct vstab_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::map<std::string, float> last_ms;
+    // staging for small per-call parameter tables (pinned host + device mirror)
+    ScratchBuf h_params, d_params;
+    hipEvent_t ev_params_free = nullptr;  // recorded after the H2D copy of h_params
+    // DIS / fit workspaces (grow-only)
+    ScratchBuf d_dis, d_fit, h_fit, d_gray_tmp;
+};
+
+// Upload `bytes` of host data through the pinned staging buffer; returns device pointer.
+int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** dev_out);
+
+struct KernelTimer {
+    vstab_ctx* ctx;
+    const char* kind;
+    KernelTimer(vstab_ctx* c, const char* k) : ctx(c), kind(k) {
+        if (ctx->timing) (void)hipEventRecord(ctx->ev_start, ctx->stream);
+    }
+    ~KernelTimer() {
+        if (ctx->timing) {
+            (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+            (void)hipEventSynchronize(ctx->ev_stop);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop);
+            ctx->last_ms[kind] = ms;
+        }
+    }
+};
+
+// cv::invert for a 3x3 CV_64F matrix (closed form); returns false (and zeros) if singular.
+bool vstab_invert3x3(const double* S, double* D);

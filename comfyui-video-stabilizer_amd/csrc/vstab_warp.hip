@@ -1,0 +1,456 @@
+// vstab_warp.hip -- perspective/similarity warp with padding mask and multi-sample motion blur.
+//
+// Replaces the OpenCV calls of nodes/video_stabilizer_flow.py:560-588 (F13) and
+// nodes/motion_apply.py:75-202 (A3, A5) of the reference.  Arithmetic follows OpenCV's
+// legacy warpPerspective/remap kernels (f64 coordinate math evaluated per 64-wide block,
+// 1/32-px quantised fractions, f32 weights, left-to-right f32 sums) so that the result is
+// bit-identical to oracle/vo_warp.c.  Built with -ffp-contract=off: no FMA may be formed.
+//
+// Kernel shape (HBM-bound, 28 B of algorithmic traffic per output pixel):
+//   * one thread = 4 consecutive output pixels of one row -> 3x 16-B RGB stores + 1x 16-B mask store
+//   * one 256-thread block = 128 x 8 output tile; its bilinear source footprint (~129 x 9 px,
+//     14 KB) stays in the CU's L1, vertically adjacent tiles share a source row through L2
+//   * blockIdx is remapped so that the 8 XCDs (private L2 each) own contiguous runs of tiles
+//   * padding-pixel count: wave shuffle reduction -> LDS -> one atomic per block, only if non-zero
+#include "vstab_internal.h"
+
+namespace {
+
+constexpr int TILE_PX = 4;        // pixels per thread along x
+constexpr int TILE_TX = 32;       // threads along x
+constexpr int TILE_TY = 8;        // threads (rows) along y
+constexpr int TILE_W = TILE_TX * TILE_PX;
+constexpr int TILE_H = TILE_TY;
+constexpr int MAX_BLUR_SAMPLES = 33;
+
+struct WarpXform {   // per (frame, sample)
+    double m[9];     // inverse (output -> source) matrix, as cv::warpPerspective builds it
+    double wq;       // affine only: m8 ? 32/m8 : 0
+    double wn;       // affine only: m8 ? 1/m8 : 0
+    int affine;      // m6 == 0 && m7 == 0
+    int pad_;
+};
+
+struct WarpArgs {
+    const float* src;
+    float* dst;
+    float* mask;
+    unsigned* pad_count;
+    const WarpXform* xf;
+    int n, sh, sw, dh, dw;
+    int bw0;          // column block width of OpenCV's WarpPerspectiveInvoker
+    int bw0_pow2;     // 1 if bw0 is a power of two
+    int tiles_x, tiles_y;
+    int samples;      // 1 for the plain warp
+    int nxf_per_frame;  // sample matrices stored per frame (1 for a single-frame blur clip)
+    float b0, b1, b2;   // border colour
+    int vec_store;    // 1 if 16-B vector stores are legal (dw % 4 == 0, aligned bases)
+};
+
+__device__ __forceinline__ int clamp_round_i32(double v)
+{
+    // std::max((double)INT_MIN, std::min((double)INT_MAX, v)) followed by cvRound
+    const double hi = 2147483647.0, lo = -2147483648.0;
+    double m = (v < hi) ? v : hi;
+    double r = (lo < m) ? m : lo;
+    return (int)__builtin_rint(r);
+}
+
+__device__ __forceinline__ int sat_short(int v)
+{
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}
+
+// initInterTab1D(INTER_CUBIC): A = -0.75, x = i/32, same operation order as OpenCV's interpolateCubic
+__device__ __forceinline__ void cubic_coeffs(int i, float* c)
+{
+    const float A = -0.75f;
+    const float x = i * (1.f / 32);
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+struct Px { float r, g, b; };
+
+__device__ __forceinline__ Px load_px(const float* p)
+{
+    Px v;
+    __builtin_memcpy(&v, p, 12);
+    return v;
+}
+
+template <int INTERP>
+__device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int sw, int X, int Y,
+                                        float b0, float b1, float b2)
+{
+    const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const int fx = X & 31, fy = Y & 31;
+    Px o;
+    if (INTERP == VSTAB_INTERP_BILINEAR) {
+        const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1;
+        const float wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
+        const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
+        if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
+            const float* p = S + ((size_t)sy * sw + sx) * 3;
+            float r0[6], r1[6];
+            __builtin_memcpy(r0, p, 24);
+            __builtin_memcpy(r1, p + (size_t)sw * 3, 24);
+            o.r = r0[0] * w0 + r0[3] * w1 + r1[0] * w2 + r1[3] * w3;
+            o.g = r0[1] * w0 + r0[4] * w1 + r1[1] * w2 + r1[4] * w3;
+            o.b = r0[2] * w0 + r0[5] * w1 + r1[2] * w2 + r1[5] * w3;
+            return o;
+        }
+        if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+            o.r = b0; o.g = b1; o.b = b2;
+            return o;
+        }
+        const bool x0ok = sx >= 0 && sx < sw, x1ok = sx + 1 >= 0 && sx + 1 < sw;
+        const bool y0ok = sy >= 0 && sy < sh, y1ok = sy + 1 >= 0 && sy + 1 < sh;
+        const Px bd = {b0, b1, b2};
+        const Px v0 = (x0ok && y0ok) ? load_px(S + ((size_t)sy * sw + sx) * 3) : bd;
+        const Px v1 = (x1ok && y0ok) ? load_px(S + ((size_t)sy * sw + sx + 1) * 3) : bd;
+        const Px v2 = (x0ok && y1ok) ? load_px(S + ((size_t)(sy + 1) * sw + sx) * 3) : bd;
+        const Px v3 = (x1ok && y1ok) ? load_px(S + ((size_t)(sy + 1) * sw + sx + 1) * 3) : bd;
+        o.r = v0.r * w0 + v1.r * w1 + v2.r * w2 + v3.r * w3;
+        o.g = v0.g * w0 + v1.g * w1 + v2.g * w2 + v3.g * w3;
+        o.b = v0.b * w0 + v1.b * w1 + v2.b * w2 + v3.b * w3;
+        return o;
+    } else {
+        float cx[4], cy[4];
+        cubic_coeffs(fx, cx);
+        cubic_coeffs(fy, cy);
+        const int x0 = sx - 1, y0 = sy - 1;
+        const unsigned width1 = (unsigned)(sw - 3 > 0 ? sw - 3 : 0);
+        const unsigned height1 = (unsigned)(sh - 3 > 0 ? sh - 3 : 0);
+        if ((unsigned)x0 < width1 && (unsigned)y0 < height1) {
+            const float* p = S + ((size_t)y0 * sw + x0) * 3;
+            float sr = 0.f, sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float row[12];
+                __builtin_memcpy(row, p + (size_t)i * sw * 3, 48);
+                const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+                const float tr = row[0] * w0 + row[3] * w1 + row[6] * w2 + row[9] * w3;
+                const float tg = row[1] * w0 + row[4] * w1 + row[7] * w2 + row[10] * w3;
+                const float tb = row[2] * w0 + row[5] * w1 + row[8] * w2 + row[11] * w3;
+                if (i == 0) { sr = tr; sg = tg; sb = tb; }
+                else { sr += tr; sg += tg; sb += tb; }
+            }
+            o.r = sr; o.g = sg; o.b = sb;
+            return o;
+        }
+        if (x0 >= sw || x0 + 4 <= 0 || y0 >= sh || y0 + 4 <= 0) {
+            o.r = b0; o.g = b1; o.b = b2;
+            return o;
+        }
+        float sr = b0, sg = b1, sb = b2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int yy = y0 + i;
+            if (yy < 0 || yy >= sh) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int xx = x0 + j;
+                if (xx < 0 || xx >= sw) continue;
+                const Px v = load_px(S + ((size_t)yy * sw + xx) * 3);
+                const float w = cy[i] * cx[j];
+                sr += (v.r - b0) * w;
+                sg += (v.g - b1) * w;
+                sb += (v.b - b2) * w;
+            }
+        }
+        o.r = sr; o.g = sg; o.b = sb;
+        return o;
+    }
+}
+
+__device__ __forceinline__ Px sample_exact(const float* __restrict__ S, int sh, int sw, float fsx, float fsy,
+                                           float b0, float b1, float b2)
+{
+    Px o;
+    const float flx = __builtin_floorf(fsx), fly = __builtin_floorf(fsy);
+    const bool bad = !(fsx == fsx) || !(fsy == fsy) || flx >= 2.0e9f || flx <= -2.0e9f || fly >= 2.0e9f || fly <= -2.0e9f;
+    const int ix = bad ? 0 : (int)flx, iy = bad ? 0 : (int)fly;
+    const float ax = fsx - ix, ay = fsy - iy;
+    if (bad || ix >= sw || ix + 1 < 0 || iy >= sh || iy + 1 < 0) {
+        o.r = b0; o.g = b1; o.b = b2;
+        return o;
+    }
+    const bool x0ok = ix >= 0 && ix < sw, x1ok = ix + 1 >= 0 && ix + 1 < sw;
+    const bool y0ok = iy >= 0 && iy < sh, y1ok = iy + 1 >= 0 && iy + 1 < sh;
+    const Px bd = {b0, b1, b2};
+    const Px p00 = (x0ok && y0ok) ? load_px(S + ((size_t)iy * sw + ix) * 3) : bd;
+    const Px p01 = (x1ok && y0ok) ? load_px(S + ((size_t)iy * sw + ix + 1) * 3) : bd;
+    const Px p10 = (x0ok && y1ok) ? load_px(S + ((size_t)(iy + 1) * sw + ix) * 3) : bd;
+    const Px p11 = (x1ok && y1ok) ? load_px(S + ((size_t)(iy + 1) * sw + ix + 1) * 3) : bd;
+    float v0, v1;
+    v0 = p00.r + ax * (p01.r - p00.r); v1 = p10.r + ax * (p11.r - p10.r); o.r = v0 + ay * (v1 - v0);
+    v0 = p00.g + ax * (p01.g - p00.g); v1 = p10.g + ax * (p11.g - p10.g); o.g = v0 + ay * (v1 - v0);
+    v0 = p00.b + ax * (p01.b - p00.b); v1 = p10.b + ax * (p11.b - p10.b); o.b = v0 + ay * (v1 - v0);
+    return o;
+}
+
+// XCD-aware bijective remap of the linear block id (8 XCDs, round-robin dispatch):
+// blocks that share an XCD get a contiguous run of logical tile ids.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+    const unsigned q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+    const unsigned base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + i;
+}
+
+template <int INTERP, int SUBPIX, bool BLUR, bool WITH_MASK>
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
+{
+    __shared__ unsigned s_cnt[4];
+    const unsigned nblk = gridDim.x;
+    const unsigned t = xcd_remap(blockIdx.x, nblk);
+    const unsigned tiles_per_frame = (unsigned)a.tiles_x * a.tiles_y;
+    const int frame = t / tiles_per_frame;
+    const unsigned tr = t - frame * tiles_per_frame;
+    const int tile_y = tr / a.tiles_x, tile_x = tr - tile_y * a.tiles_x;
+    const int tx = threadIdx.x & (TILE_TX - 1), ty = threadIdx.x >> 5;
+    const int x0 = tile_x * TILE_W + tx * TILE_PX;
+    const int y = tile_y * TILE_H + ty;
+    const bool active = (y < a.dh) && (x0 < a.dw);
+    const int npx = active ? (a.dw - x0 < TILE_PX ? a.dw - x0 : TILE_PX) : 0;
+
+    const float* __restrict__ S = a.src + (size_t)frame * a.sh * a.sw * 3;
+    const int S_count = BLUR ? a.samples : 1;
+    const int nxf = BLUR ? a.nxf_per_frame : 1;
+
+    float acc[TILE_PX][3];
+    float cov[TILE_PX];
+#pragma unroll
+    for (int p = 0; p < TILE_PX; p++) { acc[p][0] = acc[p][1] = acc[p][2] = 0.f; cov[p] = 0.f; }
+
+    if (active) {
+        // OpenCV evaluates the row-start terms per 64-wide column block (x0 % 4 == 0, so the
+        // 4 pixels of a thread never straddle a block).
+        int xb;
+        if (a.bw0 >= a.dw) xb = 0;
+        else if (a.bw0_pow2) xb = x0 & ~(a.bw0 - 1);
+        else xb = (x0 / a.bw0) * a.bw0;
+        const double dxb = (double)xb, dy = (double)y;
+
+        for (int k = 0; k < nxf; k++) {
+            const WarpXform* __restrict__ xf = a.xf + (size_t)frame * nxf + k;
+            const double m0 = xf->m[0], m1 = xf->m[1], m2 = xf->m[2];
+            const double m3 = xf->m[3], m4 = xf->m[4], m5 = xf->m[5];
+            const double m6 = xf->m[6], m7 = xf->m[7], m8 = xf->m[8];
+            const bool affine = xf->affine != 0;
+            const double X0 = m0 * dxb + m1 * dy + m2;
+            const double Y0 = m3 * dxb + m4 * dy + m5;
+            const double W0 = m6 * dxb + m7 * dy + m8;
+            float mf[9];
+            if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
+            }
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) {
+                if (p >= npx) continue;
+                const int x = x0 + p;
+                const double dx1 = (double)(x - xb);
+                const double Xn = X0 + m0 * dx1, Yn = Y0 + m3 * dx1;
+                double Wq, Wn;
+                if (affine) { Wq = xf->wq; Wn = xf->wn; }
+                else {
+                    const double W = W0 + m6 * dx1;
+                    Wq = (W != 0.0) ? 32.0 / W : 0.0;
+                    Wn = (W != 0.0) ? 1.0 / W : 0.0;
+                }
+                Px v;
+                if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
+                    const float w = x * mf[6] + y * mf[7] + mf[8];
+                    const float fsx = (x * mf[0] + y * mf[1] + mf[2]) / w;
+                    const float fsy = (x * mf[3] + y * mf[4] + mf[5]) / w;
+                    v = sample_exact(S, a.sh, a.sw, fsx, fsy, a.b0, a.b1, a.b2);
+                } else {
+                    const int X = clamp_round_i32(Xn * Wq);
+                    const int Y = clamp_round_i32(Yn * Wq);
+                    v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
+                }
+                if (BLUR) { acc[p][0] += v.r; acc[p][1] += v.g; acc[p][2] += v.b; }
+                else { acc[p][0] = v.r; acc[p][1] = v.g; acc[p][2] = v.b; }
+                if (WITH_MASK) {
+                    const int nx = sat_short(clamp_round_i32(Xn * Wn));
+                    const int ny = sat_short(clamp_round_i32(Yn * Wn));
+                    const float c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
+                    if (BLUR) cov[p] += c; else cov[p] = c;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    float mk[TILE_PX];
+    unsigned padded = 0;
+    if (BLUR) {
+        const float fs = (float)S_count;
+#pragma unroll
+        for (int p = 0; p < TILE_PX; p++) {
+            acc[p][0] = acc[p][0] / fs; acc[p][1] = acc[p][1] / fs; acc[p][2] = acc[p][2] / fs;
+            float m = 1.0f - cov[p] / fs;
+            mk[p] = (m < 1e-3f) ? 0.f : m;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < TILE_PX; p++) {
+            float m = 1.0f - cov[p];
+            mk[p] = (m < 1e-3f) ? 0.f : m;
+            if (WITH_MASK && p < npx) padded += (mk[p] > 0.5f) ? 1u : 0u;
+        }
+    }
+
+    if (active) {
+        const size_t pix = ((size_t)frame * a.dh + y) * a.dw + x0;
+        float* __restrict__ D = a.dst + pix * 3;
+        if (a.vec_store) {
+            float4* D4 = reinterpret_cast<float4*>(D);
+            D4[0] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[1][0]);
+            D4[1] = make_float4(acc[1][1], acc[1][2], acc[2][0], acc[2][1]);
+            D4[2] = make_float4(acc[2][2], acc[3][0], acc[3][1], acc[3][2]);
+            if (WITH_MASK) *reinterpret_cast<float4*>(a.mask + pix) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) {
+                if (p >= npx) continue;
+                D[p * 3 + 0] = acc[p][0]; D[p * 3 + 1] = acc[p][1]; D[p * 3 + 2] = acc[p][2];
+                if (WITH_MASK) a.mask[pix + p] = mk[p];
+            }
+        }
+    }
+
+    if (WITH_MASK && !BLUR && a.pad_count != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) padded += __shfl_down(padded, off);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = padded;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (total) atomicAdd(a.pad_count + frame, total);
+        }
+    }
+}
+
+template <int INTERP, int SUBPIX, bool BLUR>
+void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t st)
+{
+    if (with_mask) hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+template <bool BLUR>
+int launch_warp(const WarpArgs& a, int interp, int subpix, bool with_mask, hipStream_t st)
+{
+    const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
+    VSTAB_REQUIRE(blocks > 0 && blocks < 0x7fffffffULL, "warp: grid of %llu blocks is out of range", blocks);
+    const unsigned grid = (unsigned)blocks;
+    if (interp == VSTAB_INTERP_BICUBIC) launch_mask<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st);
+    else if (subpix == VSTAB_SUBPIX_EXACT) launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT, BLUR>(a, with_mask, grid, st);
+    else launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st);
+    VSTAB_HIP(hipGetLastError());
+    return 0;
+}
+
+void fill_xform(const float* m32, WarpXform* xf)
+{
+    double M[9];
+    for (int i = 0; i < 9; i++) M[i] = (double)m32[i];
+    vstab_invert3x3(M, xf->m);
+    xf->affine = (xf->m[6] == 0.0 && xf->m[7] == 0.0) ? 1 : 0;
+    const double W = xf->m[8];
+    xf->wq = (W != 0.0) ? 32.0 / W : 0.0;
+    xf->wn = (W != 0.0) ? 1.0 / W : 0.0;
+    xf->pad_ = 0;
+}
+
+int check_common(const char* who, vstab_ctx* ctx, const void* src, int n, int sh, int sw, const void* mats,
+                 int dh, int dw, int interp, const float* border, int subpix, const void* dst)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
+    VSTAB_REQUIRE(src && mats && border && dst, "%s: NULL pointer argument", who);
+    VSTAB_REQUIRE(n > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0, "%s: non-positive size (n=%d src=%dx%d out=%dx%d)", who, n, sw, sh, dw, dh);
+    VSTAB_REQUIRE(sh <= 32767 && sw <= 32767, "%s: source larger than 32767 px is not representable in OpenCV's short maps", who);
+    VSTAB_REQUIRE(interp == VSTAB_INTERP_BILINEAR || interp == VSTAB_INTERP_BICUBIC, "%s: unknown interpolation %d", who, interp);
+    VSTAB_REQUIRE(subpix == VSTAB_SUBPIX_Q5 || subpix == VSTAB_SUBPIX_EXACT, "%s: unknown subpix mode %d", who, subpix);
+    VSTAB_REQUIRE(!(subpix == VSTAB_SUBPIX_EXACT && interp == VSTAB_INTERP_BICUBIC), "%s: exact sub-pixel mode exists for bilinear only", who);
+    return 0;
+}
+
+void fill_geometry(WarpArgs& a, int n, int sh, int sw, int dh, int dw, const float* border, const float* dst, const float* mask)
+{
+    a.n = n; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw;
+    const int BLOCK_SZ = 32;
+    int bh0 = BLOCK_SZ / 2 < dh ? BLOCK_SZ / 2 : dh;
+    int bw0 = BLOCK_SZ * BLOCK_SZ / bh0 < dw ? BLOCK_SZ * BLOCK_SZ / bh0 : dw;
+    a.bw0 = bw0;
+    a.bw0_pow2 = (bw0 & (bw0 - 1)) == 0;
+    a.tiles_x = (dw + TILE_W - 1) / TILE_W;
+    a.tiles_y = (dh + TILE_H - 1) / TILE_H;
+    a.b0 = border[0]; a.b1 = border[1]; a.b2 = border[2];
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
+    a.vec_store = ((dw & 3) == 0 && aligned) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w, const float* matrices,
+                                int out_h, int out_w, int interp, const float* border_rgb, int subpix, float* dst,
+                                float* mask, uint32_t* pad_count)
+{
+    if (int rc = check_common("vstab_warp_batch", ctx, src, n, src_h, src_w, matrices, out_h, out_w, interp, border_rgb, subpix, dst)) return rc;
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    std::vector<WarpXform> xf((size_t)n);
+    for (int i = 0; i < n; i++) fill_xform(matrices + (size_t)i * 9, &xf[i]);
+    void* d_xf = nullptr;
+    if (vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(WarpXform), &d_xf)) return 1;
+
+    WarpArgs a{};
+    a.src = src; a.dst = dst; a.mask = mask; a.pad_count = pad_count;
+    a.xf = static_cast<const WarpXform*>(d_xf);
+    a.samples = 1; a.nxf_per_frame = 1;
+    fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
+    if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+    KernelTimer timer(ctx, "warp");
+    return launch_warp<false>(a, interp, subpix, mask != nullptr, ctx->stream);
+}
+
+extern "C" int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                                     const double* matrices, const double* ts, int samples, int out_h, int out_w,
+                                     int interp, const float* border_rgb, int subpix, float* dst, float* mask)
+{
+    if (int rc = check_common("vstab_warp_blur_batch", ctx, src, n, src_h, src_w, matrices, out_h, out_w, interp, border_rgb, subpix, dst)) return rc;
+    VSTAB_REQUIRE(ts != nullptr, "vstab_warp_blur_batch: ts is NULL");
+    VSTAB_REQUIRE(samples >= 1 && samples <= MAX_BLUR_SAMPLES, "vstab_warp_blur_batch: samples=%d outside [1,%d]", samples, MAX_BLUR_SAMPLES);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    // motion_apply.py:125-134: a single-frame clip yields one sample matrix (still divided by `samples`)
+    const int per_frame = (n <= 1) ? 1 : samples;
+    std::vector<WarpXform> xf((size_t)n * per_frame);
+    for (int i = 0; i < n; i++) {
+        const double* base = matrices + (size_t)i * 9;
+        double delta[9];
+        if (n > 1) {
+            if (i < n - 1) for (int j = 0; j < 9; j++) delta[j] = matrices[(size_t)(i + 1) * 9 + j] - base[j];
+            else for (int j = 0; j < 9; j++) delta[j] = base[j] - matrices[(size_t)(i - 1) * 9 + j];
+        }
+        for (int k = 0; k < per_frame; k++) {
+            float m32[9];
+            for (int j = 0; j < 9; j++) m32[j] = (n > 1) ? (float)(base[j] + delta[j] * ts[k]) : (float)base[j];
+            fill_xform(m32, &xf[(size_t)i * per_frame + k]);
+        }
+    }
+    void* d_xf = nullptr;
+    if (vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(WarpXform), &d_xf)) return 1;
+
+    WarpArgs a{};
+    a.src = src; a.dst = dst; a.mask = mask; a.pad_count = nullptr;
+    a.xf = static_cast<const WarpXform*>(d_xf);
+    a.samples = samples; a.nxf_per_frame = per_frame;
+    fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
+    KernelTimer timer(ctx, "warp_blur");
+    return launch_warp<true>(a, interp, subpix, mask != nullptr, ctx->stream);
+}

@@ -1,0 +1,316 @@
+"""ctypes binding of libvstab.so (include/vstab.h) -- the only compute path of this package.
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible every
+entry point raises.  torch tensors are used as the device-memory container only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "lib" / "libvstab.so"
+
+INTERP = {"bilinear": 0, "bicubic": 1}
+SUBPIX = {"q5": 0, "exact": 1}
+MODES = {"translation": 0, "similarity": 1, "perspective": 2}
+MODE_NAMES = ("translation", "similarity", "perspective")
+
+# Sub-pixel model used by the node path; see include/vstab.h (vstab_subpix) and DESIGN.md.
+DEFAULT_SUBPIX = os.environ.get("VSTAB_SUBPIX", "q5")
+
+
+class VstabError(RuntimeError):
+    pass
+
+
+class FitRecord(C.Structure):
+    _fields_ = [
+        ("matrix", C.c_float * 9),
+        ("confidence", C.c_float),
+        ("residual", C.c_float),
+        ("accepted", C.c_int32),
+        ("computed", C.c_int32),
+        ("valid_points", C.c_int32),
+        ("total_points", C.c_int32),
+    ]
+
+
+_SIGNATURES = {
+    "vstab_abi_version": (C.c_int, []),
+    "vstab_last_error": (C.c_char_p, []),
+    "vstab_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vstab_destroy": (C.c_int, [C.c_void_p]),
+    "vstab_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vstab_synchronize": (C.c_int, [C.c_void_p]),
+    "vstab_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "vstab_last_kernel_ms": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]),
+    "vstab_warp_batch": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "vstab_warp_blur_batch": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+         C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "vstab_gray_downscale": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_dis_flow_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vstab_sample_fit_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_trajectory": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
+         C.c_void_p],
+    ),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library():
+    """Load libvstab.so; raises VstabError if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise VstabError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU fallback."
+            )
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here means the ABI and the header diverged
+            fn.restype = res
+            fn.argtypes = args
+        if lib.vstab_abi_version() != 1:
+            raise VstabError(f"libvstab ABI version {lib.vstab_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().vstab_last_error()
+        raise VstabError(f"{what} failed ({rc}): {msg.decode('utf-8', 'replace') if msg else 'unknown error'}")
+
+
+def _dev_ptr(t) -> int:
+    return int(t.data_ptr())
+
+
+class Context:
+    """One libvstab context bound to one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device: Optional[int] = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise VstabError("no MI355X / HIP device visible: the stabilizer hot path has no CPU fallback")
+        self.torch = torch
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.lib = load_library()
+        handle = C.c_void_p()
+        _check(self.lib.vstab_create(C.byref(handle), self.device_index), "vstab_create")
+        self.handle = handle
+        self.use_torch_stream()
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.vstab_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self) -> None:
+        stream = self.torch.cuda.current_stream(self.device)
+        _check(self.lib.vstab_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), "vstab_set_stream")
+
+    def synchronize(self) -> None:
+        _check(self.lib.vstab_synchronize(self.handle), "vstab_synchronize")
+
+    def set_timing(self, enabled: bool) -> None:
+        _check(self.lib.vstab_set_timing(self.handle, 1 if enabled else 0), "vstab_set_timing")
+
+    def last_kernel_ms(self, kind: str) -> float:
+        out = C.c_float()
+        _check(self.lib.vstab_last_kernel_ms(self.handle, kind.encode(), C.byref(out)), "vstab_last_kernel_ms")
+        return float(out.value)
+
+    # ------------------------------------------------------------------ helpers
+    def _as_device_frames(self, frames):
+        torch = self.torch
+        if not isinstance(frames, torch.Tensor):
+            frames = torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32))
+        if frames.dtype != torch.float32:
+            frames = frames.to(torch.float32)
+        if frames.device != self.device:
+            frames = frames.to(self.device, non_blocking=True)
+        return frames.contiguous()
+
+    # ------------------------------------------------------------------ warp
+    def warp_batch(self, frames, matrices, out_size, interp="bilinear", border=(0.0, 0.0, 0.0),
+                   subpix=None, want_mask=True, want_count=False, out=None, out_mask=None):
+        """frames [N,H,W,3] f32 (device or host) -> (dst [N,h,w,3], mask [N,h,w] | None, counts [N] | None)."""
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        if ch != 3:
+            raise VstabError(f"warp_batch expects 3-channel frames, got {ch}")
+        out_w, out_h = int(out_size[0]), int(out_size[1])
+        m = np.ascontiguousarray(matrices, dtype=np.float32).reshape(n, 9)
+        b = np.ascontiguousarray(border, dtype=np.float32).reshape(3)
+        dst = out if out is not None else torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=self.device)
+        mask = None
+        if want_mask:
+            mask = out_mask if out_mask is not None else torch.empty((n, out_h, out_w), dtype=torch.float32, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device) if (want_count and want_mask) else None
+        self.use_torch_stream()
+        _check(
+            self.lib.vstab_warp_batch(
+                self.handle, _dev_ptr(src), n, sh, sw, m.ctypes.data, out_h, out_w, INTERP[interp], b.ctypes.data,
+                SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst), _dev_ptr(mask) if mask is not None else None,
+                _dev_ptr(counts) if counts is not None else None,
+            ),
+            "vstab_warp_batch",
+        )
+        return dst, mask, counts
+
+    def warp_blur_batch(self, frames, matrices64, out_size, blur, samples, interp="bilinear",
+                        border=(0.0, 0.0, 0.0), subpix=None, want_mask=True, out=None, out_mask=None):
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        if ch != 3:
+            raise VstabError(f"warp_blur_batch expects 3-channel frames, got {ch}")
+        out_w, out_h = int(out_size[0]), int(out_size[1])
+        m = np.ascontiguousarray(matrices64, dtype=np.float64).reshape(n, 9)
+        ts = np.ascontiguousarray(np.linspace(0.0, float(blur), int(samples), dtype=np.float64))
+        b = np.ascontiguousarray(border, dtype=np.float32).reshape(3)
+        dst = out if out is not None else torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=self.device)
+        mask = None
+        if want_mask:
+            mask = out_mask if out_mask is not None else torch.empty((n, out_h, out_w), dtype=torch.float32, device=self.device)
+        self.use_torch_stream()
+        _check(
+            self.lib.vstab_warp_blur_batch(
+                self.handle, _dev_ptr(src), n, sh, sw, m.ctypes.data, ts.ctypes.data, int(samples), out_h, out_w,
+                INTERP[interp], b.ctypes.data, SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst),
+                _dev_ptr(mask) if mask is not None else None,
+            ),
+            "vstab_warp_blur_batch",
+        )
+        return dst, mask
+
+    # ------------------------------------------------------------------ estimation
+    def gray_downscale(self, frames, work_size):
+        """frames [N,H,W,3] f32 -> gray u8 [N,work_h,work_w] (work_size=(w,h) or None for full size)."""
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        if ch != 3:
+            raise VstabError(f"gray_downscale expects 3-channel frames, got {ch}")
+        ww, wh = (sw, sh) if work_size is None else (int(work_size[0]), int(work_size[1]))
+        gray = torch.empty((n, wh, ww), dtype=torch.uint8, device=self.device)
+        self.use_torch_stream()
+        _check(self.lib.vstab_gray_downscale(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray)),
+               "vstab_gray_downscale")
+        return gray
+
+    def dis_flow_batch(self, gray, sample_step=8, want_full=False, want_grid=True):
+        """gray u8 [N,h,w] (device) -> (flow [N-1,h,w,2] | None, grid_flow [N-1,gh,gw,2] | None)."""
+        torch = self.torch
+        if gray.device != self.device:
+            gray = gray.to(self.device)
+        gray = gray.contiguous()
+        n, h, w = gray.shape
+        pairs = n - 1
+        if pairs < 1:
+            raise VstabError("dis_flow_batch needs at least two frames")
+        gh, gw = (h + sample_step - 1) // sample_step, (w + sample_step - 1) // sample_step
+        flow = torch.empty((pairs, h, w, 2), dtype=torch.float32, device=self.device) if want_full else None
+        grid = torch.empty((pairs, gh, gw, 2), dtype=torch.float32, device=self.device) if want_grid else None
+        self.use_torch_stream()
+        _check(
+            self.lib.vstab_dis_flow_batch(
+                self.handle, _dev_ptr(gray), n, h, w, _dev_ptr(flow) if flow is not None else None,
+                _dev_ptr(grid) if grid is not None else None, int(sample_step),
+            ),
+            "vstab_dis_flow_batch",
+        )
+        return flow, grid
+
+    def sample_fit_batch(self, grid_flow, step, requested_mode):
+        """grid_flow [P,gh,gw,2] (device) -> list over pairs of {mode_name: FitRecord-like dict}."""
+        if grid_flow.device != self.device:
+            grid_flow = grid_flow.to(self.device)
+        grid_flow = grid_flow.contiguous()
+        pairs, gh, gw, _ = grid_flow.shape
+        recs = (FitRecord * (pairs * 3))()
+        self.use_torch_stream()
+        _check(
+            self.lib.vstab_sample_fit_batch(
+                self.handle, _dev_ptr(grid_flow), pairs, gh, gw, int(step), MODES[requested_mode], C.byref(recs)),
+            "vstab_sample_fit_batch",
+        )
+        out = []
+        for p in range(pairs):
+            entry = {}
+            for mi, name in enumerate(MODE_NAMES):
+                r = recs[p * 3 + mi]
+                if not r.computed:
+                    continue
+                entry[name] = {
+                    "matrix": np.array(list(r.matrix), dtype=np.float32).reshape(3, 3),
+                    "confidence": float(r.confidence),
+                    "residual": float(r.residual),
+                    "accepted": bool(r.accepted),
+                    "valid_points": int(r.valid_points),
+                    "total_points": int(r.total_points),
+                }
+            out.append(entry)
+        return out
+
+    def trajectory(self, deltas, smooth, fps, strength, camera_lock):
+        d = np.ascontiguousarray(deltas, dtype=np.float64)
+        n = d.shape[0] + 1
+        p = d.shape[1]
+        path = np.zeros((n, p), np.float64)
+        target = np.zeros((n, p), np.float64)
+        _check(
+            self.lib.vstab_trajectory(self.handle, d.ctypes.data, n, p, float(smooth), float(fps), float(strength),
+                                      1 if camera_lock else 0, path.ctypes.data, target.ctypes.data),
+            "vstab_trajectory",
+        )
+        return path, target
+
+
+_default_ctx: dict = {}
+
+
+def default_context() -> Context:
+    """Per-process context on the current torch device."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise VstabError("no MI355X / HIP device visible: the stabilizer hot path has no CPU fallback")
+    idx = torch.cuda.current_device()
+    ctx = _default_ctx.get(idx)
+    if ctx is None:
+        ctx = Context(idx)
+        _default_ctx[idx] = ctx
+    return ctx

@@ -1,0 +1,151 @@
+/*
+ * vstab.h -- C ABI of libvstab.so, the MI355X (gfx950) implementation of the
+ * dense-flow stabilization hot path of nomadoor/ComfyUI-Video-Stabilizer.
+ *
+ * The reference is pure Python and has no FFI of its own; every entry point
+ * below replaces a group of OpenCV/NumPy calls made by the reference's Python
+ * (file:line cited per function, paths relative to the reference root).  The
+ * Python host layer (comfyui-video-stabilizer_amd/) binds these with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every call returns 0 on success, non-zero on failure;
+ *     vstab_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are HIP device pointers owned by the caller (e.g.
+ *     torch.Tensor.data_ptr()); "host" pointers are ordinary host memory.
+ *     The library never frees caller memory and never returns owned memory.
+ *   - work is enqueued on the context's stream (vstab_set_stream; default: the
+ *     null stream).  Calls that return host results synchronise that stream;
+ *     the others are asynchronous.
+ *   - images are row-major, channel-last: frames [N,H,W,3] f32 0..1,
+ *     masks [N,H,W] f32, gray [N,h,w] u8, flow [P,h,w,2] f32 (x,y).
+ *   - 3x3 matrices are row-major, 9 values.
+ */
+#ifndef VSTAB_H
+#define VSTAB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSTAB_ABI_VERSION 1
+
+typedef struct vstab_ctx vstab_ctx;
+
+enum vstab_interp { VSTAB_INTERP_BILINEAR = 0, VSTAB_INTERP_BICUBIC = 1 };
+/* sub-pixel model of the interpolating warp: Q5 = OpenCV legacy kernels (source
+ * coordinates rounded to 1/32 px), EXACT = full f32 coordinates (OpenCV >= 4.11
+ * INTER_LINEAR kernels; bilinear only). */
+enum vstab_subpix { VSTAB_SUBPIX_Q5 = 0, VSTAB_SUBPIX_EXACT = 1 };
+enum vstab_mode { VSTAB_MODE_TRANSLATION = 0, VSTAB_MODE_SIMILARITY = 1, VSTAB_MODE_PERSPECTIVE = 2 };
+
+/* ---- context ------------------------------------------------------------ */
+int vstab_abi_version(void);
+const char* vstab_last_error(void);
+/* device < 0: use the current HIP device */
+int vstab_create(vstab_ctx** out, int device);
+int vstab_destroy(vstab_ctx* ctx);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
+int vstab_set_stream(vstab_ctx* ctx, void* hip_stream);
+int vstab_synchronize(vstab_ctx* ctx);
+/* seconds the stream spent between the library's internal start/stop events of the
+ * most recent call of the named kind ("warp","warp_blur","gray","dis","fit");
+ * requires vstab_set_timing(ctx,1).  Used by bench.py for the roofline line. */
+int vstab_set_timing(vstab_ctx* ctx, int enabled);
+int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out);
+
+/* ---- F13 / A3: per-frame warp with padding mask ---------------------------
+ * Replaces the loop at nodes/video_stabilizer_flow.py:560-588 and
+ * nodes/motion_apply.py:92-120:
+ *   cv2.warpPerspective(frame, M, (out_w,out_h), INTER_LINEAR|INTER_CUBIC, BORDER_CONSTANT, rgb)
+ *   cv2.warpPerspective(ones,  M, (out_w,out_h), INTER_NEAREST, BORDER_CONSTANT, 0)
+ *   mask = 1 - (content > 0.5); mask[mask < 1e-3] = 0
+ * src        dev  [n, src_h, src_w, 3] f32
+ * matrices   host [n, 9] f32, forward (source -> output) as the reference passes them
+ * border_rgb host [3] f32 (padding_rgb / 255 computed in f32)
+ * dst        dev  [n, out_h, out_w, 3] f32
+ * mask       dev  [n, out_h, out_w] f32 or NULL (masks_zero path, motion_apply.py:103-106)
+ * pad_count  dev  [n] u32 or NULL: number of mask==1 pixels per frame
+ *                 (mask.mean() = count/(out_h*out_w), flow.py:587)
+ */
+int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                     const float* matrices, int out_h, int out_w, int interp,
+                     const float* border_rgb, int subpix, float* dst, float* mask,
+                     uint32_t* pad_count);
+
+/* ---- A5: multi-sample motion-blur warp -------------------------------------
+ * Replaces nodes/motion_apply.py:125-202 (_blurred_matrix_samples +
+ * _warp_with_motion_blur).  matrices: host [n,9] f64 motion matrices; the
+ * library forms the S sample matrices M[i] + (M[i+1]-M[i])*t_k, t = linspace(0,
+ * blur, S) in f64, casts each to f32 and inverts in f64 exactly as the plain warp does.
+ * ts: host [samples] f64 = numpy.linspace(0, blur, samples) supplied by the caller
+ * (keeps NumPy's own linspace rounding on the Python side of the boundary).
+ * Output frame = sum_k warp_k / float(samples); mask = 1 - coverage_sum/samples,
+ * values < 1e-3 -> 0.  mask may be NULL.
+ */
+int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                          const double* matrices, const double* ts, int samples, int out_h,
+                          int out_w, int interp, const float* border_rgb, int subpix,
+                          float* dst, float* mask);
+
+/* ---- F2: grayscale + INTER_AREA downscale to the estimation size ------------
+ * Replaces nodes/stabilizer_utils.py:236-242 (_make_gray: cv2.cvtColor RGB2GRAY
+ * on f32, clip(gray*255,0,255).astype(uint8)) and :271-276 (cv2.resize INTER_AREA).
+ * work_h/work_w == src_h/src_w means "no downscale" (working_size None).
+ * frames dev [n,src_h,src_w,3] f32 -> gray dev [n,work_h,work_w] u8.
+ */
+int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w,
+                         int work_h, int work_w, uint8_t* gray);
+
+/* ---- F3 (+F4): DIS dense optical flow over consecutive pairs ---------------
+ * Replaces cv2.DISOpticalFlow (PRESET_MEDIUM, finestScale 2, patchSize 8,
+ * patchStride 4, spatial propagation) created at nodes/video_stabilizer_flow.py:82-86
+ * and called at :140, for pairs (i, i+1), i in [0, n-1).
+ * gray        dev [n,h,w] u8
+ * flow        dev [n-1,h,w,2] f32 or NULL (full field; tests / debugging)
+ * grid_flow   dev [n-1,gh,gw,2] f32 or NULL: the flow sampled at y=0,step,.. x=0,step,..
+ *             (gh = ceil(h/step), gw = ceil(w/step)) -- the only values the
+ *             reference consumes (flow.py:141-147)
+ */
+int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w,
+                         float* flow, float* grid_flow, int sample_step);
+
+/* ---- F4 + F5: model fit on the sampled flow -------------------------------
+ * Replaces nodes/video_stabilizer_flow.py:141-210 for every pair: RANSAC
+ * homography (cv2.findHomography 2.5 px / 2000 / 0.992, accept >= 0.15),
+ * RANSAC similarity (cv2.estimateAffinePartial2D 2.0 px / 2000 / 0.992, accept
+ * >= 0.1) and per-axis median translation.  All candidate models at or below
+ * `requested_mode` are evaluated for every pair; the host applies the
+ * sequential "sticky active_mode" rule (flow.py:324-339) to pick one.
+ * grid_flow dev [pairs,gh,gw,2]; step = sample stride used to build the grid.
+ * results host [pairs * 3] records indexed [pair*3 + mode].
+ */
+typedef struct vstab_fit_record {
+    float matrix[9];   /* 3x3 f32 at working resolution */
+    float confidence;
+    float residual;
+    int32_t accepted;  /* 1 if this mode's acceptance test passed */
+    int32_t computed;  /* 1 if this mode was evaluated */
+    int32_t valid_points; /* finite samples (flow.py:150-154) */
+    int32_t total_points;
+} vstab_fit_record;
+int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw,
+                           int step, int requested_mode, vstab_fit_record* results);
+
+/* ---- F7 + F8: trajectory (prefix sum, box smoothing, strength blend), fp64 ---
+ * Replaces nodes/video_stabilizer_flow.py:356-371 and
+ * nodes/stabilizer_utils.py:361-383 (_smooth_path: moving average, edge padded,
+ * window from fps).  deltas host [n-1,p]; path/target host [n,p].
+ */
+int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double smooth,
+                     double fps, double strength, int camera_lock, double* path,
+                     double* target);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSTAB_H */

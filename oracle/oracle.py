@@ -1,0 +1,156 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  It is the checker, never the product: the product path lives in
+comfyui-video-stabilizer_amd/ and talks to libvstab.so (HIP) only.
+
+The C sources restate the OpenCV algorithms behind the reference's call sites
+(see oracle/vo_common.h); parity against a real OpenCV is unpinned.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "libvstab_oracle.so"
+
+INTERP = {"bilinear": 0, "bicubic": 1}
+SUBPIX = {"q5": 0, "exact": 1}
+MODES = {"translation": 0, "similarity": 1, "perspective": 2}
+MODE_NAMES = {v: k for k, v in MODES.items()}
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (a few seconds)."""
+    if force or not _LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class DisParams(C.Structure):
+    _fields_ = [
+        ("finest_scale", C.c_int),
+        ("patch_size", C.c_int),
+        ("patch_stride", C.c_int),
+        ("grad_descent_iter", C.c_int),
+        ("var_iter", C.c_int),
+        ("alpha", C.c_float),
+        ("delta", C.c_float),
+        ("gamma", C.c_float),
+        ("use_mean_norm", C.c_int),
+        ("use_spatial_prop", C.c_int),
+    ]
+
+
+class FitResult(C.Structure):
+    _fields_ = [
+        ("matrix", C.c_float * 9),
+        ("mode", C.c_int),
+        ("confidence", C.c_float),
+        ("residual", C.c_float),
+        ("valid", C.c_int),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(_LIB_PATH))
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def set_threads(n: int) -> None:
+    os.environ["OMP_NUM_THREADS"] = str(int(n))
+
+
+# ---------------------------------------------------------------- warp
+def invert3x3(m):
+    m = np.ascontiguousarray(m, dtype=np.float64).reshape(9)
+    out = np.zeros(9, dtype=np.float64)
+    lib().vo_invert3x3(_ptr(m, C.c_double), _ptr(out, C.c_double))
+    return out.reshape(3, 3)
+
+
+def interp_tables():
+    lin = np.zeros(64, np.float32)
+    cub = np.zeros(128, np.float32)
+    lib().vo_interp_tables(_ptr(lin, C.c_float), _ptr(cub, C.c_float))
+    return lin.reshape(32, 2), cub.reshape(32, 4)
+
+
+def warp_frame(src, matrix, out_size, interp="bilinear", border=(0.0, 0.0, 0.0), subpix="q5", want_coverage=True):
+    """cv2.warpPerspective(src, matrix(f32), (w,h), flags, BORDER_CONSTANT, border) + nearest coverage."""
+    src = _f32(src)
+    sh, sw, _ = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    m = _f32(matrix).reshape(9)
+    b = _f32(border).reshape(3)
+    dst = np.empty((dh, dw, 3), np.float32)
+    cov = np.empty((dh, dw), np.float32) if want_coverage else None
+    lib().vo_warp_frame(
+        _ptr(src, C.c_float), sh, sw, _ptr(m, C.c_float), dh, dw, INTERP[interp], _ptr(b, C.c_float),
+        SUBPIX[subpix], _ptr(dst, C.c_float), _ptr(cov, C.c_float) if cov is not None else None,
+    )
+    return dst, cov
+
+
+def warp_clip(src, matrices, out_size, interp="bilinear", border=(0.0, 0.0, 0.0), subpix="q5", want_mask=True):
+    src = _f32(src)
+    n, sh, sw, _ = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    m = _f32(matrices).reshape(n, 9)
+    b = _f32(border).reshape(3)
+    dst = np.empty((n, dh, dw, 3), np.float32)
+    mask = np.empty((n, dh, dw), np.float32) if want_mask else None
+    cnt = np.zeros(n, np.uint32)
+    lib().vo_warp_clip(
+        _ptr(src, C.c_float), n, sh, sw, _ptr(m, C.c_float), dh, dw, INTERP[interp], _ptr(b, C.c_float),
+        SUBPIX[subpix], _ptr(dst, C.c_float), _ptr(mask, C.c_float) if mask is not None else None,
+        _ptr(cnt, C.c_uint32),
+    )
+    return dst, mask, cnt
+
+
+def warp_blur_clip(src, matrices64, out_size, blur, samples, interp="bilinear", border=(0.0, 0.0, 0.0), subpix="q5", want_mask=True):
+    src = _f32(src)
+    n, sh, sw, _ = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    m = np.ascontiguousarray(matrices64, dtype=np.float64).reshape(n, 9)
+    b = _f32(border).reshape(3)
+    dst = np.empty((n, dh, dw, 3), np.float32)
+    mask = np.empty((n, dh, dw), np.float32) if want_mask else None
+    lib().vo_warp_blur_clip.argtypes = [
+        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+        C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+    ]
+    lib().vo_warp_blur_clip(
+        src.ctypes.data, n, sh, sw, m.ctypes.data, dh, dw, INTERP[interp], b.ctypes.data, SUBPIX[subpix],
+        float(blur), int(samples), dst.ctypes.data, mask.ctypes.data if mask is not None else None,
+    )
+    return dst, mask
+
+
+def linspace(a, b, n):
+    out = np.zeros(n, np.float64)
+    lib().vo_linspace.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p]
+    lib().vo_linspace(float(a), float(b), int(n), out.ctypes.data)
+    return out

@@ -1,0 +1,81 @@
+/*
+ * vstab_oracle.h -- entry points of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ * See vo_common.h for what the oracle is and what pins it.  Product code must
+ * never include, link or load anything from oracle/.
+ */
+#ifndef VSTAB_ORACLE_H
+#define VSTAB_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VO_INTERP_BILINEAR = 0, VO_INTERP_BICUBIC = 1 };
+enum { VO_SUBPIX_Q5 = 0, VO_SUBPIX_EXACT = 1 };
+enum { VO_MODE_TRANSLATION = 0, VO_MODE_SIMILARITY = 1, VO_MODE_PERSPECTIVE = 2 };
+
+/* ---- warp (vo_warp.c) ---- */
+int vo_invert3x3(const double* S, double* D);
+void vo_interp_tables(float* lin, float* cub);
+void vo_warp_frame(const float* src, int sh, int sw, const float* M32, int dh, int dw, int interp,
+                   const float* border, int subpix, float* dst, float* coverage);
+void vo_warp_frame_inv(const float* src, int sh, int sw, const double* Minv, int dh, int dw,
+                       int interp, const float* border, int subpix, float* dst, float* coverage);
+void vo_warp_clip(const float* src, int n, int sh, int sw, const float* M32, int dh, int dw,
+                  int interp, const float* border, int subpix, float* dst, float* mask,
+                  unsigned* pad_count);
+void vo_linspace(double a, double b, int n, double* out);
+void vo_blur_sample_matrices(const double* matrices, int n, int idx, double blur, int samples,
+                             float* out32);
+void vo_warp_blur_clip(const float* src, int n, int sh, int sw, const double* matrices, int dh,
+                       int dw, int interp, const float* border, int subpix, double blur,
+                       int samples, float* dst, float* mask);
+
+/* ---- gray + resize (vo_gray.c) ---- */
+void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray);
+void vo_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+void vo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst, int dh, int dw);
+void vo_gray_for_estimation(const float* rgb, int n, int h, int w, int wh, int ww, int fused_body,
+                            uint8_t* out);
+
+/* ---- DIS optical flow (vo_dis.c) ---- */
+typedef struct vo_dis_params {
+    int finest_scale;      /* 2  (flow.py:83) */
+    int patch_size;        /* 8  (flow.py:84) */
+    int patch_stride;      /* 4  (flow.py:85) */
+    int grad_descent_iter; /* 25 (PRESET_MEDIUM) */
+    int var_iter;          /* 5  (PRESET_MEDIUM) */
+    float alpha, delta, gamma; /* 20, 5, 10 */
+    int use_mean_norm;     /* 1 */
+    int use_spatial_prop;  /* 1 (flow.py:86) */
+} vo_dis_params;
+void vo_dis_default_params(vo_dis_params* p);
+/* I0, I1: u8 [h,w]; flow out: f32 [h,w,2] */
+int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis_params* p,
+                float* flow);
+/* batch over consecutive pairs of a gray clip [n,h,w]; flow [n-1,h,w,2] */
+int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, float* flow);
+int vo_dis_coarsest_scale(int h, int w, int patch_size);
+
+/* ---- sampling + model fit (vo_fit.c) ---- */
+typedef struct vo_fit_result {
+    float matrix[9];
+    int mode;          /* VO_MODE_* actually used; identity fallback reports translation */
+    float confidence;
+    float residual;
+    int valid;         /* 0 => "<12 valid samples" / total failure identity path */
+} vo_fit_result;
+/* flow [h,w,2]; restates flow.py:141-210 starting from requested mode */
+void vo_fit_from_flow(const float* flow, int h, int w, int step, int requested_mode,
+                      vo_fit_result* out);
+int vo_estimate_affine_partial2d(const float* from, const float* to, int count, double thresh,
+                                 int max_iters, double confidence, int refine_iters,
+                                 double* M /*2x3*/, uint8_t* inliers);
+int vo_find_homography_ransac(const float* from, const float* to, int count, double thresh,
+                              int max_iters, double confidence, double* H /*3x3*/,
+                              uint8_t* inliers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

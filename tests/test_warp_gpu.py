@@ -1,0 +1,115 @@
+"""GPU parity: vstab_warp_batch / vstab_warp_blur_batch (HIP, via the C ABI) vs oracle/vo_warp.c.
+
+Tolerance: bit-exact (np.array_equal) -- both sides evaluate the same f64 coordinate math and the
+same left-to-right f32 sums with FMA contraction disabled."""
+
+import numpy as np
+import pytest
+
+from tests.util import synth_frames, test_matrices as make_matrices
+
+pytestmark = pytest.mark.gpu
+
+BORDER = (np.array([127, 127, 127], np.float32) / 255.0)
+
+CASES = [
+    # (n, src_h, src_w, out_h, out_w, kind)
+    (3, 24, 32, 24, 32, "identity"),
+    (3, 24, 32, 24, 32, "translation"),
+    (2, 45, 73, 45, 73, "similarity"),
+    (2, 45, 73, 51, 80, "perspective"),      # odd sizes -> scalar store path
+    (2, 120, 212, 120, 212, "similarity"),   # > 1 tile, vector store path
+    (2, 120, 212, 130, 224, "perspective"),
+    (1, 24, 32, 24, 32, "far"),
+    (2, 10, 150, 10, 150, "similarity"),     # dh < 16 -> 102-wide OpenCV column blocks
+]
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("case", CASES)
+def test_warp_matches_oracle(ctx, oracle, case, interp):
+    n, sh, sw, dh, dw, kind = case
+    frames = synth_frames(n, sh, sw, seed=n + sh)
+    mats = make_matrices(n, sw, sh, kind).astype(np.float32)
+    ref, ref_mask, ref_cnt = oracle.warp_clip(frames, mats, (dw, dh), interp=interp, border=BORDER)
+    dst, mask, cnt = ctx.warp_batch(frames, mats, (dw, dh), interp=interp, border=BORDER, subpix="q5",
+                                    want_mask=True, want_count=True)
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
+
+
+@pytest.mark.parametrize("case", CASES[:6])
+def test_warp_exact_mode_matches_oracle(ctx, oracle, case):
+    n, sh, sw, dh, dw, kind = case
+    frames = synth_frames(n, sh, sw, seed=7)
+    mats = make_matrices(n, sw, sh, kind).astype(np.float32)
+    ref, ref_mask, _ = oracle.warp_clip(frames, mats, (dw, dh), interp="bilinear", border=BORDER, subpix="exact")
+    dst, mask, _ = ctx.warp_batch(frames, mats, (dw, dh), interp="bilinear", border=BORDER, subpix="exact")
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+def test_warp_masks_zero_path(ctx, oracle):
+    frames = synth_frames(2, 45, 73, seed=3)
+    mats = make_matrices(2, 73, 45, "similarity").astype(np.float32)
+    ref, _, _ = oracle.warp_clip(frames, mats, (73, 45), border=BORDER, want_mask=False)
+    dst, mask, cnt = ctx.warp_batch(frames, mats, (73, 45), border=BORDER, want_mask=False)
+    assert mask is None and cnt is None
+    assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("interp,samples", [("bilinear", 5), ("bicubic", 17), ("bilinear", 33)])
+@pytest.mark.parametrize("kind", ["similarity", "perspective"])
+def test_blur_matches_oracle(ctx, oracle, interp, samples, kind):
+    n, sh, sw = 3, 45, 73
+    frames = synth_frames(n, sh, sw, seed=11)
+    mats = make_matrices(n, sw, sh, kind)
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (sw, sh), 0.5, samples, interp=interp, border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (sw, sh), 0.5, samples, interp=interp, border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+def test_blur_single_frame_quirk(ctx, oracle):
+    """motion_apply.py:125-127,195: a 1-frame clip yields one sample but is still divided by S."""
+    frames = synth_frames(1, 24, 32, seed=5)
+    mats = make_matrices(1, 32, 24, "translation")
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (32, 24), 0.5, 9, border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (32, 24), 0.5, 9, border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+def test_identity_is_passthrough(ctx):
+    """KA1 (check_motion_meta.py:289-311): identity -> output == input within 1e-6, mask all zero."""
+    frames = synth_frames(3, 24, 32, seed=2)
+    mats = np.tile(np.eye(3, dtype=np.float32), (3, 1, 1))
+    dst, mask, cnt = ctx.warp_batch(frames, mats, (32, 24), border=BORDER, want_count=True)
+    assert np.max(np.abs(dst.cpu().numpy() - frames)) <= 1e-6
+    assert float(mask.max()) == 0.0 and int(cnt.sum()) == 0
+
+
+def test_full_size_properties(ctx):
+    """1080p (BASELINE configs[1] frame size): identity passthrough + pure integer translation
+    equals an array shift, independent of the oracle."""
+    import torch
+
+    n, h, w = 2, 1080, 1920
+    g = torch.Generator(device="cpu").manual_seed(0)
+    frames = torch.rand((n, h, w, 3), generator=g, dtype=torch.float32)
+    eye = np.tile(np.eye(3, dtype=np.float32), (n, 1, 1))
+    dst, mask, cnt = ctx.warp_batch(frames, eye, (w, h), border=BORDER, want_count=True)
+    assert torch.equal(dst.cpu(), frames)
+    assert int(cnt.sum()) == 0
+    shift = eye.copy()
+    shift[:, 0, 2] = 5.0
+    shift[:, 1, 2] = -3.0
+    dst, mask, cnt = ctx.warp_batch(frames, shift, (w, h), border=BORDER, want_count=True)
+    d = dst.cpu()
+    assert torch.equal(d[:, : h - 3, 5:, :], frames[:, 3:, : w - 5, :])
+    m = mask.cpu()
+    assert float(m[:, : h - 3, 5:].max()) == 0.0
+    assert float(m[:, h - 3 :, :].min()) == 1.0 and float(m[:, :, :5].min()) == 1.0
+    expect = h * w - (h - 3) * (w - 5)
+    assert cnt.cpu().tolist() == [expect] * n

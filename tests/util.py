@@ -1,0 +1,49 @@
+"""Shared synthetic inputs for the tests (seeded, no reference code involved)."""
+
+import numpy as np
+
+
+def synth_frames(n, h, w, seed=0):
+    """Smooth gradient + checker + noise, float32 in [0,1], shape [n,h,w,3]."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = np.empty((n, h, w, 3), np.float32)
+    for i in range(n):
+        base = 0.5 + 0.25 * np.sin(xx * 0.11 + i * 0.3) * np.cos(yy * 0.07 - i * 0.2)
+        chk = (((xx // 7).astype(np.int32) + (yy // 5).astype(np.int32) + i) % 2).astype(np.float32) * 0.2
+        for c in range(3):
+            noise = rng.random((h, w), dtype=np.float32) * 0.15
+            out[i, ..., c] = np.clip(base * (0.8 + 0.1 * c) + chk + noise - 0.1, 0.0, 1.0)
+    return out
+
+
+def similarity(tx, ty, theta, scale, cx=0.0, cy=0.0):
+    c, s = np.cos(theta) * scale, np.sin(theta) * scale
+    m = np.array([[c, -s, tx], [s, c, ty], [0, 0, 1]], np.float64)
+    t = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1]], np.float64)
+    ti = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1]], np.float64)
+    return t @ m @ ti
+
+
+def test_matrices(n, w, h, kind, seed=1):
+    rng = np.random.default_rng(seed)
+    mats = []
+    for i in range(n):
+        if kind == "identity":
+            m = np.eye(3)
+        elif kind == "translation":
+            m = similarity(rng.uniform(-9, 9), rng.uniform(-7, 7), 0.0, 1.0)
+        elif kind == "similarity":
+            m = similarity(rng.uniform(-12, 12), rng.uniform(-8, 8), rng.uniform(-0.06, 0.06),
+                           rng.uniform(0.95, 1.06), w / 2, h / 2)
+        elif kind == "perspective":
+            m = similarity(rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-0.04, 0.04),
+                           rng.uniform(0.97, 1.03), w / 2, h / 2)
+            m[2, 0] = rng.uniform(-2e-4, 2e-4)
+            m[2, 1] = rng.uniform(-2e-4, 2e-4)
+        elif kind == "far":
+            m = similarity(3.0 * w, -2.0 * h, 0.1, 1.0)
+        else:
+            raise ValueError(kind)
+        mats.append(m)
+    return np.stack(mats).astype(np.float64)
