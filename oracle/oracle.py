@@ -154,3 +154,42 @@ def linspace(a, b, n):
     lib().vo_linspace.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p]
     lib().vo_linspace(float(a), float(b), int(n), out.ctypes.data)
     return out
+
+
+# ---------------------------------------------------------------- gray / resize
+def rgb2gray_u8(rgb, fused_body=True):
+    rgb = _f32(rgb)
+    h, w, _ = rgb.shape
+    out = np.empty((h, w), np.uint8)
+    lib().vo_rgb2gray_u8(_ptr(rgb, C.c_float), h, w, 1 if fused_body else 0, _ptr(out, C.c_uint8))
+    return out
+
+
+def resize_area_u8(src, out_size):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    out = np.empty((dh, dw), np.uint8)
+    lib().vo_resize_area_u8(_ptr(src, C.c_uint8), sh, sw, _ptr(out, C.c_uint8), dh, dw)
+    return out
+
+
+def resize_linear_f32(src, out_size):
+    src = _f32(src)
+    if src.ndim == 2:
+        src = src[..., None]
+    sh, sw, cn = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    out = np.empty((dh, dw, cn), np.float32)
+    lib().vo_resize_linear_f32(_ptr(src, C.c_float), sh, sw, cn, _ptr(out, C.c_float), dh, dw)
+    return out
+
+
+def gray_for_estimation(frames, work_size, fused_body=True):
+    """[_make_gray_for_estimation(f, work_size) for f in frames]; work_size=(w,h) or None."""
+    frames = _f32(frames)
+    n, h, w, _ = frames.shape
+    ww, wh = (w, h) if work_size is None else (int(work_size[0]), int(work_size[1]))
+    out = np.empty((n, wh, ww), np.uint8)
+    lib().vo_gray_for_estimation(_ptr(frames, C.c_float), n, h, w, wh, ww, 1 if fused_body else 0, _ptr(out, C.c_uint8))
+    return out

@@ -1,0 +1,41 @@
+"""GPU parity: vstab_gray_downscale vs oracle/vo_gray.c -- bit-exact (u8)."""
+
+import numpy as np
+import pytest
+
+from tests.util import synth_frames
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (n, h, w, work (w,h) or None)
+    (2, 48, 64, None),          # no downscale (<= 960 px): gray only
+    (2, 45, 73, None),          # odd width: scalar tail of the gray conversion, unaligned stores
+    (2, 108, 192, (96, 54)),    # exact 2x (the 1080p -> 960x540 case in miniature)
+    (2, 216, 384, (96, 54)),    # exact 4x (the 4K case in miniature)
+    (2, 90, 150, (50, 30)),     # exact 3x -> generic integer path
+    (2, 72, 128, (96, 54)),     # 1.333x -> general area path (720p -> 960x540 in miniature)
+    (1, 67, 121, (60, 33)),     # ragged general ratio
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gray_downscale_matches_oracle(ctx, oracle, case):
+    n, h, w, work = case
+    frames = synth_frames(n, h, w, seed=h)
+    ref = oracle.gray_for_estimation(frames, work)
+    got = ctx.gray_downscale(frames, work).cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_gray_1080p_properties(ctx):
+    """Full BASELINE size: constant frames -> constant gray (truncation of 255*Y), any ratio."""
+    import torch
+
+    frames = torch.full((2, 1080, 1920, 3), 0.5, dtype=torch.float32)
+    g = ctx.gray_downscale(frames, (960, 540)).cpu().numpy()
+    assert g.shape == (2, 540, 960) and np.all(g == 127)
+    frames4k = torch.full((1, 2160, 3840, 3), 1.0, dtype=torch.float32)
+    g = ctx.gray_downscale(frames4k, (960, 540)).cpu().numpy()
+    assert np.all(g == 255) or np.all(g == 254)
