@@ -1,9 +1,6 @@
 // Entry points whose HIP implementation has not landed yet: fail loudly, never fall back.
 #include "vstab_internal.h"
 extern "C" {
-#ifndef HAVE_DIS
-int vstab_dis_flow_batch(vstab_ctx*, const uint8_t*, int, int, int, float*, float*, int) { vstab_set_error("vstab_dis_flow_batch: not built"); return 99; }
-#endif
 #ifndef HAVE_FIT
 int vstab_sample_fit_batch(vstab_ctx*, const float*, int, int, int, int, int, vstab_fit_record*) { vstab_set_error("vstab_sample_fit_batch: not built"); return 99; }
 #endif

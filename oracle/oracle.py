@@ -193,3 +193,40 @@ def gray_for_estimation(frames, work_size, fused_body=True):
     out = np.empty((n, wh, ww), np.uint8)
     lib().vo_gray_for_estimation(_ptr(frames, C.c_float), n, h, w, wh, ww, 1 if fused_body else 0, _ptr(out, C.c_uint8))
     return out
+
+
+# ---------------------------------------------------------------- DIS optical flow
+def dis_params(**overrides):
+    p = DisParams()
+    lib().vo_dis_default_params(C.byref(p))
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def dis_coarsest_scale(h, w, patch_size=8):
+    return int(lib().vo_dis_coarsest_scale(int(h), int(w), int(patch_size)))
+
+
+def dis_flow(i0, i1, params=None):
+    """cv2.DISOpticalFlow(...).calc(i0, i1, None) -> [h,w,2] f32."""
+    i0 = np.ascontiguousarray(i0, dtype=np.uint8)
+    i1 = np.ascontiguousarray(i1, dtype=np.uint8)
+    h, w = i0.shape
+    p = params or dis_params()
+    flow = np.empty((h, w, 2), np.float32)
+    rc = lib().vo_dis_calc(_ptr(i0, C.c_uint8), _ptr(i1, C.c_uint8), h, w, C.byref(p), _ptr(flow, C.c_float))
+    if rc != 0:
+        raise ValueError(f"vo_dis_calc: unsupported configuration (rc={rc})")
+    return flow
+
+
+def dis_flow_clip(gray, params=None):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    n, h, w = gray.shape
+    p = params or dis_params()
+    flow = np.empty((n - 1, h, w, 2), np.float32)
+    rc = lib().vo_dis_calc_clip(_ptr(gray, C.c_uint8), n, h, w, C.byref(p), _ptr(flow, C.c_float))
+    if rc != 0:
+        raise ValueError(f"vo_dis_calc_clip: unsupported configuration (rc={rc})")
+    return flow
