@@ -1,0 +1,374 @@
+// vstab_fit.hip -- F4+F5: model fit on the grid-sampled flow, one 256-thread block per frame pair.
+//
+// Replaces nodes/video_stabilizer_flow.py:141-210 of the reference: the stride-8 sampling of the
+// dense flow, cv2.estimateAffinePartial2D (RANSAC 2.0 px / 2000 / 0.992 + 10 LM iterations),
+// cv2.findHomography (RANSAC 2.5 px / 2000 / 0.992 + DLT on inliers + 10 LM iterations) and the
+// per-axis median translation.
+//
+// RANSAC keeps OpenCV's sequential semantics (RNG seeded with 2^64-1, adaptive iteration count)
+// but runs data-parallel: one lane replays the RNG and draws a batch of K minimal samples, K lanes
+// build the K models, all 256 lanes score every model against every sample in one pass over the
+// points (integer inlier counts -> order independent), then one lane replays OpenCV's
+// "best so far / update niters" loop over the batch.  The final least-squares refit is the closed
+// form of what the 10 LM iterations converge to (the similarity problem is linear): fp64 sums
+// reduced in a fixed tree, 4x4 solve on one lane.
+#include "vstab_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int FIT_THREADS = 256;
+constexpr int RANSAC_BATCH = 32;
+constexpr int MAX_SORT = 16384;
+
+struct Rng { unsigned long long state; };
+__device__ __forceinline__ unsigned rng_next(Rng& r)
+{
+    r.state = (unsigned long long)(unsigned)r.state * 4164903690ULL + (unsigned)(r.state >> 32);
+    return (unsigned)r.state;
+}
+__device__ __forceinline__ int rng_uniform(Rng& r, int a, int b) { return a == b ? a : (int)(rng_next(r) % (unsigned)(b - a) + a); }
+
+__device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > 2.2250738585072014e-308 ? 1. - p : 2.2250738585072014e-308;
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)__builtin_rint(num / denom);
+}
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch /* >= 4 */)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const T total = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    __syncthreads();
+    return total;
+}
+
+struct FitArgs {
+    const float* grid_flow;   // [pairs][gh][gw][2]
+    int* vmap;                // [pairs][gh*gw] compacted index -> grid index
+    vstab_fit_record* out;    // [pairs*3]
+    int pairs, gh, gw, step, requested_mode;
+};
+
+__device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, int step, int g, float& px, float& py, float& cx, float& cy)
+{
+    const int gy = g / gw, gx = g - gy * gw;
+    px = (float)(gx * step);
+    py = (float)(gy * step);
+    cx = px + F[(size_t)g * 2];
+    cy = py + F[(size_t)g * 2 + 1];
+}
+
+__device__ void identity_record(vstab_fit_record& r, int nv, int total)
+{
+    for (int i = 0; i < 9; i++) r.matrix[i] = (i % 4 == 0) ? 1.f : 0.f;
+    r.confidence = 0.0; r.residual = 0.0; r.accepted = 0; r.computed = 0; r.valid_points = nv; r.total_points = total;
+}
+
+__device__ void bitonic_sort_lds(float* a, int n2)
+{
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n2; i += FIT_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
+{
+    __shared__ float s_sort[MAX_SORT];
+    __shared__ double s_model[RANSAC_BATCH][6];
+    __shared__ float s_modelf[RANSAC_BATCH][6];
+    __shared__ int s_idx[RANSAC_BATCH][2];
+    __shared__ int s_cnt[RANSAC_BATCH];
+    __shared__ double s_red[8];
+    __shared__ int s_redi[8];
+    __shared__ int s_scan[FIT_THREADS];
+    __shared__ double s_best[6];
+    __shared__ int s_ctl[4];   // 0: done flag, 1: niters, 2: iter, 3: maxGood
+    __shared__ Rng s_rng;
+
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int total = a.gh * a.gw;
+    const float* __restrict__ F = a.grid_flow + (size_t)pair * total * 2;
+    int* __restrict__ vmap = a.vmap + (size_t)pair * total;
+    vstab_fit_record* out = a.out + (size_t)pair * 3;
+
+    // ---- validity scan (ordered compaction, flow.py:150-152) ----
+    const int per = (total + FIT_THREADS - 1) / FIT_THREADS;
+    const int g0 = tid * per, g1 = min(g0 + per, total);
+    int local = 0;
+    for (int g = g0; g < g1; g++) {
+        float px, py, cx, cy;
+        load_point(F, a.gw, a.step, g, px, py, cx, cy);
+        local += (isfinite(cx) && isfinite(cy)) ? 1 : 0;
+    }
+    s_scan[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < FIT_THREADS; i++) { const int v = s_scan[i]; s_scan[i] = acc; acc += v; }
+        s_redi[0] = acc;
+    }
+    __syncthreads();
+    const int nv = s_redi[0];
+    {
+        int o = s_scan[tid];
+        for (int g = g0; g < g1; g++) {
+            float px, py, cx, cy;
+            load_point(F, a.gw, a.step, g, px, py, cx, cy);
+            if (isfinite(cx) && isfinite(cy)) vmap[o++] = g;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) identity_record(out[tid], nv, total);
+    if (nv < 12) return;   // flow.py:153-154 (block-uniform)
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- similarity: RANSAC over 2-point samples (AffinePartial2DEstimatorCallback) ----
+    if (a.requested_mode >= VSTAB_MODE_SIMILARITY && nv >= 3) {
+        if (tid == 0) { s_rng.state = ~0ULL; s_ctl[0] = 0; s_ctl[1] = 2000; s_ctl[2] = 0; s_ctl[3] = 0; }
+        __syncthreads();
+        const float thr = (float)(2.0 * 2.0);
+        while (true) {
+            if (tid == 0) {
+                Rng r = s_rng;
+                for (int c = 0; c < RANSAC_BATCH; c++) {
+                    const int i0 = rng_uniform(r, 0, nv);
+                    int i1;
+                    do { i1 = rng_uniform(r, 0, nv); } while (i1 == i0);
+                    s_idx[c][0] = i0; s_idx[c][1] = i1;
+                }
+                s_rng = r;
+            }
+            __syncthreads();
+            if (tid < RANSAC_BATCH) {
+                float x1f, y1f, X1f, Y1f, x2f, y2f, X2f, Y2f;
+                load_point(F, a.gw, a.step, vmap[s_idx[tid][0]], x1f, y1f, X1f, Y1f);
+                load_point(F, a.gw, a.step, vmap[s_idx[tid][1]], x2f, y2f, X2f, Y2f);
+                const double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f, X1 = X1f, Y1 = Y1f, X2 = X2f, Y2 = Y2f;
+                const double d = 1. / ((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+                const double S0 = d * ((X1 - X2) * (x1 - x2) + (Y1 - Y2) * (y1 - y2));
+                const double S1 = d * ((Y1 - Y2) * (x1 - x2) - (X1 - X2) * (y1 - y2));
+                const double S2 = d * ((Y1 - Y2) * (x1 * y2 - x2 * y1) - (X1 * y2 - X2 * y1) * (y1 - y2) - (X1 * x2 - X2 * x1) * (x1 - x2));
+                const double S3 = d * (-(X1 - X2) * (x1 * y2 - x2 * y1) - (Y1 * x2 - Y2 * x1) * (x1 - x2) - (Y1 * y2 - Y2 * y1) * (y1 - y2));
+                const double M[6] = {S0, -S1, S2, S1, S0, S3};
+                for (int k = 0; k < 6; k++) { s_model[tid][k] = M[k]; s_modelf[tid][k] = (float)M[k]; }
+                s_cnt[tid] = 0;
+            }
+            __syncthreads();
+            // score every model of the batch in one pass over the points
+            int cnt[RANSAC_BATCH];
+#pragma unroll
+            for (int c = 0; c < RANSAC_BATCH; c++) cnt[c] = 0;
+            for (int k = tid; k < nv; k += FIT_THREADS) {
+                float px, py, cx, cy;
+                load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+#pragma unroll
+                for (int c = 0; c < RANSAC_BATCH; c++) {
+                    const float ea = s_modelf[c][0] * px + s_modelf[c][1] * py + s_modelf[c][2] - cx;
+                    const float eb = s_modelf[c][3] * px + s_modelf[c][4] * py + s_modelf[c][5] - cy;
+                    cnt[c] += (ea * ea + eb * eb <= thr) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < RANSAC_BATCH; c++) {
+                int v = cnt[c];
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+                if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[c], v);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int niters = s_ctl[1], iter = s_ctl[2], maxGood = s_ctl[3];
+                int c = 0;
+                for (; c < RANSAC_BATCH && iter < niters; c++, iter++) {
+                    const int good = s_cnt[c];
+                    if (good > (maxGood > 1 ? maxGood : 1)) {
+                        for (int k = 0; k < 6; k++) s_best[k] = s_model[c][k];
+                        maxGood = good;
+                        niters = ransac_update_num_iters(0.992, (double)(nv - good) / nv, 2, niters);
+                    }
+                }
+                s_ctl[1] = niters; s_ctl[2] = iter; s_ctl[3] = maxGood;
+                s_ctl[0] = (iter >= niters) ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ctl[0]) break;
+        }
+        const int maxGood = s_ctl[3];
+        if (maxGood > 0) {
+            // inliers of the best minimal-sample model -> closed-form least squares (what the LM refinement converges to)
+            const float F0 = (float)s_best[0], F1 = (float)s_best[1], F2 = (float)s_best[2];
+            const float F3 = (float)s_best[3], F4 = (float)s_best[4], F5 = (float)s_best[5];
+            double sxx = 0, sx = 0, sy = 0, sX = 0, sY = 0, sxX = 0, syX = 0;
+            int ninl = 0;
+            for (int k = tid; k < nv; k += FIT_THREADS) {
+                float px, py, cx, cy;
+                load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+                const float ea = F0 * px + F1 * py + F2 - cx;
+                const float eb = F3 * px + F4 * py + F5 - cy;
+                if (ea * ea + eb * eb <= thr) {
+                    const double x = px, y = py, X = cx, Y = cy;
+                    sxx += x * x + y * y; sx += x; sy += y; sX += X; sY += Y;
+                    sxX += x * X + y * Y; syX += x * Y - y * X;
+                    ninl++;
+                }
+            }
+            sxx = block_sum(sxx, s_red); sx = block_sum(sx, s_red); sy = block_sum(sy, s_red);
+            sX = block_sum(sX, s_red); sY = block_sum(sY, s_red); sxX = block_sum(sxX, s_red); syX = block_sum(syX, s_red);
+            ninl = block_sum(ninl, s_redi);
+            if (tid == 0) {
+                // normal equations of [x -y 1 0; y x 0 1] (a, b, tx, ty) = (X, Y)
+                double A[4][5] = {{sxx, 0, sx, sy, sxX}, {0, sxx, -sy, sx, syX}, {sx, -sy, (double)ninl, 0, sX}, {sy, sx, 0, (double)ninl, sY}};
+                bool ok = true;
+                for (int col = 0; col < 4 && ok; col++) {
+                    int piv = col;
+                    for (int r = col + 1; r < 4; r++) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+                    if (fabs(A[piv][col]) < 1e-300) { ok = false; break; }
+                    if (piv != col) for (int k = 0; k < 5; k++) { const double t = A[piv][k]; A[piv][k] = A[col][k]; A[col][k] = t; }
+                    for (int r = col + 1; r < 4; r++) {
+                        const double f = A[r][col] / A[col][col];
+                        for (int k = col; k < 5; k++) A[r][k] -= f * A[col][k];
+                    }
+                }
+                double sol[4] = {s_best[0], s_best[3], s_best[2], s_best[5]};
+                if (ok && ninl > 0) {
+                    for (int r = 3; r >= 0; r--) {
+                        double v = A[r][4];
+                        for (int k = r + 1; k < 4; k++) v -= A[r][k] * sol[k];
+                        sol[r] = v / A[r][r];
+                    }
+                }
+                s_best[0] = sol[0]; s_best[1] = -sol[1]; s_best[2] = sol[2];
+                s_best[3] = sol[1]; s_best[4] = sol[0]; s_best[5] = sol[3];
+            }
+            __syncthreads();
+            const double M0 = s_best[0], M1 = s_best[1], M2 = s_best[2], M3 = s_best[3], M4 = s_best[4], M5 = s_best[5];
+            double res = 0;
+            for (int k = tid; k < nv; k += FIT_THREADS) {
+                float px, py, cx, cy;
+                load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+                const double x = px, y = py;
+                res += fabs(x * M0 + y * M1 + M2 - (double)cx) + fabs(x * M3 + y * M4 + M5 - (double)cy);
+            }
+            res = block_sum(res, s_red);
+            if (tid == 0) {
+                vstab_fit_record& r = out[VSTAB_MODE_SIMILARITY];
+                r.computed = 1;
+                r.confidence = (double)maxGood / (double)nv;
+                if (r.confidence >= 0.1) {
+                    r.matrix[0] = (float)M0; r.matrix[1] = (float)M1; r.matrix[2] = (float)M2;
+                    r.matrix[3] = (float)M3; r.matrix[4] = (float)M4; r.matrix[5] = (float)M5;
+                    r.matrix[6] = 0.f; r.matrix[7] = 0.f; r.matrix[8] = 1.f;
+                    r.residual = res / (2.0 * nv);
+                    r.accepted = 1;
+                }
+            }
+        } else if (tid == 0) {
+            out[VSTAB_MODE_SIMILARITY].computed = 1;
+        }
+        __syncthreads();
+    }
+
+    // ---- translation: per-axis median of the shifts (flow.py:191-208) ----
+    {
+        int n2 = 1;
+        while (n2 < nv) n2 <<= 1;
+        float med[2];
+        for (int axis = 0; axis < 2; axis++) {
+            for (int k = tid; k < n2; k += FIT_THREADS) {
+                float v = INFINITY;
+                if (k < nv) {
+                    float px, py, cx, cy;
+                    load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+                    v = axis == 0 ? cx - px : cy - py;
+                }
+                s_sort[k] = v;
+            }
+            bitonic_sort_lds(s_sort, n2);
+            med[axis] = (nv & 1) ? s_sort[nv / 2] : (s_sort[nv / 2 - 1] + s_sort[nv / 2]) / 2.0f;
+            __syncthreads();
+        }
+        const float tx = med[0], ty = med[1];
+        double res = 0;
+        for (int k = tid; k < nv; k += FIT_THREADS) {
+            float px, py, cx, cy;
+            load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+            res += (double)__builtin_fabsf((px + tx) - cx) + (double)__builtin_fabsf((py + ty) - cy);
+        }
+        res = block_sum(res, s_red);
+        if (tid == 0) {
+            vstab_fit_record& r = out[VSTAB_MODE_TRANSLATION];
+            r.computed = 1; r.accepted = 1;
+            r.matrix[2] = tx; r.matrix[5] = ty;
+            r.confidence = (double)nv / (double)total;
+            r.residual = res / (2.0 * nv);
+        }
+    }
+}
+
+}  // namespace
+
+int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
+                         vstab_fit_record* d_out);
+
+extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw, int step,
+                                      int requested_mode, vstab_fit_record* results)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_sample_fit_batch: ctx is NULL");
+    VSTAB_REQUIRE(grid_flow && results, "vstab_sample_fit_batch: NULL pointer argument");
+    VSTAB_REQUIRE(pairs > 0 && gh > 0 && gw > 0 && step > 0, "vstab_sample_fit_batch: non-positive size");
+    VSTAB_REQUIRE(requested_mode >= VSTAB_MODE_TRANSLATION && requested_mode <= VSTAB_MODE_PERSPECTIVE, "vstab_sample_fit_batch: unknown mode %d", requested_mode);
+    VSTAB_REQUIRE((long long)gh * gw <= MAX_SORT, "vstab_sample_fit_batch: %d sample points exceed the supported %d", gh * gw, MAX_SORT);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const size_t rec_bytes = sizeof(vstab_fit_record) * (size_t)pairs * 3;
+    const size_t map_bytes = sizeof(int) * (size_t)pairs * gh * gw;
+    if (ctx->d_fit.reserve(rec_bytes + map_bytes + 512)) return 1;
+    if (ctx->h_fit.reserve(rec_bytes)) return 1;
+    char* base = static_cast<char*>(ctx->d_fit.ptr);
+    vstab_fit_record* d_out = reinterpret_cast<vstab_fit_record*>(base);
+    int* d_map = reinterpret_cast<int*>(base + ((rec_bytes + 255) & ~size_t(255)));
+    {
+        KernelTimer timer(ctx, "fit");
+        FitArgs a{grid_flow, d_map, d_out, pairs, gh, gw, step, requested_mode};
+        hipLaunchKernelGGL(fit_kernel, dim3((unsigned)pairs), dim3(FIT_THREADS), 0, ctx->stream, a);
+        VSTAB_HIP(hipGetLastError());
+        if (requested_mode >= VSTAB_MODE_PERSPECTIVE) {
+            if (int rc = vstab_fit_homography(ctx, grid_flow, d_map, pairs, gh, gw, step, d_out)) return rc;
+        }
+    }
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(results, ctx->h_fit.ptr, rec_bytes);
+    return 0;
+}
+
+// Homography RANSAC lands in a follow-up translation unit; until then fail loudly.
+#ifndef VSTAB_HAVE_HOMOGRAPHY
+int vstab_fit_homography(vstab_ctx*, const float*, const int*, int, int, int, int, vstab_fit_record*)
+{
+    vstab_set_error("vstab_sample_fit_batch: perspective (homography) fit is not built yet");
+    return 98;
+}
+#endif

@@ -32,8 +32,8 @@ class VstabError(RuntimeError):
 class FitRecord(C.Structure):
     _fields_ = [
         ("matrix", C.c_float * 9),
-        ("confidence", C.c_float),
-        ("residual", C.c_float),
+        ("confidence", C.c_double),
+        ("residual", C.c_double),
         ("accepted", C.c_int32),
         ("computed", C.c_int32),
         ("valid_points", C.c_int32),

@@ -126,8 +126,8 @@ int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int 
  */
 typedef struct vstab_fit_record {
     float matrix[9];   /* 3x3 f32 at working resolution */
-    float confidence;
-    float residual;
+    double confidence; /* inlier ratio (translation: valid/total), as the reference's Python float */
+    double residual;   /* mean |model(p) - q| over all valid samples, both axes */
     int32_t accepted;  /* 1 if this mode's acceptance test passed */
     int32_t computed;  /* 1 if this mode was evaluated */
     int32_t valid_points; /* finite samples (flow.py:150-154) */

@@ -55,8 +55,8 @@ class FitResult(C.Structure):
     _fields_ = [
         ("matrix", C.c_float * 9),
         ("mode", C.c_int),
-        ("confidence", C.c_float),
-        ("residual", C.c_float),
+        ("confidence", C.c_double),
+        ("residual", C.c_double),
         ("valid", C.c_int),
     ]
 
@@ -230,3 +230,54 @@ def dis_flow_clip(gray, params=None):
     if rc != 0:
         raise ValueError(f"vo_dis_calc_clip: unsupported configuration (rc={rc})")
     return flow
+
+
+# ---------------------------------------------------------------- model fit
+def fit_all_modes(flow, step=8, requested_mode="similarity"):
+    """All candidate models at or below `requested_mode` for one flow field [h,w,2]."""
+    flow = _f32(flow)
+    h, w, _ = flow.shape
+    recs = (FitResult * 3)()
+    nv, nt = C.c_int(), C.c_int()
+    lib().vo_fit_all_modes(_ptr(flow, C.c_float), h, w, int(step), MODES[requested_mode], recs, C.byref(nv), C.byref(nt))
+    out = {}
+    for mi in range(3):
+        r = recs[mi]
+        if r.mode < 0:
+            continue
+        out[MODE_NAMES[mi]] = {
+            "matrix": np.array(list(r.matrix), np.float32).reshape(3, 3),
+            "confidence": float(r.confidence),
+            "residual": float(r.residual),
+            "accepted": bool(r.valid),
+        }
+    return out, int(nv.value), int(nt.value)
+
+
+def fit_from_flow(flow, step=8, requested_mode="similarity"):
+    """_estimate_motion_flow's tail (flow.py:141-210): (matrix f32 3x3, mode, confidence, residual)."""
+    flow = _f32(flow)
+    h, w, _ = flow.shape
+    r = FitResult()
+    lib().vo_fit_from_flow(_ptr(flow, C.c_float), h, w, int(step), MODES[requested_mode], C.byref(r))
+    return np.array(list(r.matrix), np.float32).reshape(3, 3), MODE_NAMES[r.mode], float(r.confidence), float(r.residual)
+
+
+def estimate_affine_partial2d(src, dst, thresh=2.0, max_iters=2000, confidence=0.992, refine_iters=10):
+    src, dst = _f32(src).reshape(-1, 2), _f32(dst).reshape(-1, 2)
+    n = src.shape[0]
+    m = np.zeros(6, np.float64)
+    inl = np.zeros(n, np.uint8)
+    lib().vo_estimate_affine_partial2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    ok = lib().vo_estimate_affine_partial2d(src.ctypes.data, dst.ctypes.data, n, thresh, max_iters, confidence, refine_iters, m.ctypes.data, inl.ctypes.data)
+    return (m.reshape(2, 3) if ok else None), inl
+
+
+def find_homography(src, dst, thresh=2.5, max_iters=2000, confidence=0.992):
+    src, dst = _f32(src).reshape(-1, 2), _f32(dst).reshape(-1, 2)
+    n = src.shape[0]
+    m = np.zeros(9, np.float64)
+    inl = np.zeros(n, np.uint8)
+    lib().vo_find_homography_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    ok = lib().vo_find_homography_ransac(src.ctypes.data, dst.ctypes.data, n, thresh, max_iters, confidence, m.ctypes.data, inl.ctypes.data)
+    return (m.reshape(3, 3) if ok else None), inl

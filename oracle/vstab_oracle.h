@@ -61,13 +61,16 @@ int vo_dis_coarsest_scale(int h, int w, int patch_size);
 typedef struct vo_fit_result {
     float matrix[9];
     int mode;          /* VO_MODE_* actually used; identity fallback reports translation */
-    float confidence;
-    float residual;
-    int valid;         /* 0 => "<12 valid samples" / total failure identity path */
+    double confidence;
+    double residual;
+    int valid;         /* 1 if this mode's acceptance test passed */
 } vo_fit_result;
 /* flow [h,w,2]; restates flow.py:141-210 starting from requested mode */
 void vo_fit_from_flow(const float* flow, int h, int w, int step, int requested_mode,
                       vo_fit_result* out);
+void vo_fit_all_modes(const float* flow, int h, int w, int step, int requested_mode,
+                      vo_fit_result* rec /*3, indexed by mode; rec[m].mode == -1: not computed*/,
+                      int* valid_points, int* total_points);
 int vo_estimate_affine_partial2d(const float* from, const float* to, int count, double thresh,
                                  int max_iters, double confidence, int refine_iters,
                                  double* M /*2x3*/, uint8_t* inliers);
