@@ -1,0 +1,328 @@
+"""Whole-clip pipeline of the `Video Stabilizer Flow` node on one MI355X.
+
+Same stages, meta keys and soft-failure rules as the reference's
+nodes/video_stabilizer_flow.py:213-640 (`_stabilize_frames`), but batched over the clip:
+
+    gray+downscale (HIP) -> DIS flow for all N-1 pairs (HIP) -> model fit for all pairs (HIP)
+    -> sticky-mode selection + parameter deltas (host, sequential by definition)
+    -> prefix sum / box smoothing / blend (HIP, fp64) -> framing geometry (host fp64)
+    -> warp + padding mask + per-frame padding count for all N frames (HIP)
+
+The host keeps only what is sequential or scalar in the reference (flow.py:324-346, 360-546,
+596-640).  There is no CPU fallback for the pixel stages.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import host_math as hm
+from . import native
+from .comfy_compat import ProgressBar, check_interrupt
+from .meta_v2 import applied_motion_meta_from_stabilization_warp
+
+SAMPLE_STEP = 8  # flow.py:138
+_FALLBACK_CHAIN = {
+    "perspective": ("perspective", "similarity", "translation"),
+    "similarity": ("similarity", "translation"),
+    "translation": ("translation",),
+}
+
+
+def _attach_motion_meta(meta: Dict[str, Any], fps: float) -> Dict[str, Any]:
+    """flow.py:62-73: a failure to derive motion_meta is swallowed, the rest of the meta survives."""
+    try:
+        meta["motion_meta"] = applied_motion_meta_from_stabilization_warp(
+            meta["stabilization_warp"], fps=fps, source="estimated_flow")
+    except (KeyError, TypeError, ValueError, np.linalg.LinAlgError):
+        pass
+    return meta
+
+
+def _replay_progress(pbar, done: int, count: int, total: int, stride: int = 10) -> int:
+    """Emit the update_absolute sequence the reference's per-item loop produces (flow.py:347-351, 589-593)."""
+    pending = 0
+    for k in range(count):
+        pending += 1
+        if pending >= stride or k == count - 1:
+            done += pending
+            pbar.update_absolute(done, total)
+            pending = 0
+    return done
+
+
+def select_transitions(fit_records: List[Dict[str, Any]], requested_mode: str):
+    """Sequential 'sticky active_mode' walk over the per-pair candidate fits (flow.py:324-339, 153-210).
+
+    Returns (matrices f32 @ working resolution, modes, confidences, residuals, final active mode)."""
+    active = requested_mode
+    mats, modes, confs, resids = [], [], [], []
+    for entry in fit_records:
+        chosen = None
+        if entry:  # empty entry: fewer than 12 finite samples (flow.py:153-154)
+            for mode in _FALLBACK_CHAIN[active]:
+                cand = entry.get(mode)
+                if cand is not None and cand["accepted"]:
+                    chosen = (cand["matrix"], mode, cand["confidence"], cand["residual"])
+                    break
+        if chosen is None:
+            chosen = (np.eye(3, dtype=np.float32), "translation", 0.0, 0.0)
+        if chosen[1] != active:
+            active = chosen[1]
+        mats.append(chosen[0])
+        modes.append(chosen[1])
+        confs.append(float(chosen[2]))
+        resids.append(float(chosen[3]))
+    return mats, modes, confs, resids, active
+
+
+def estimate_transitions(ctx, device_frames, working_size, transform_mode: str):
+    """F2-F5 for frames [N,H,W,3] on the device -> per-pair candidate fits (list of dicts)."""
+    gray = ctx.gray_downscale(device_frames, working_size)
+    _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True)
+    return ctx.sample_fit_batch(grid, SAMPLE_STEP, transform_mode)
+
+
+def _fps_fields(context: hm.VideoContext, frame_rate) -> Tuple[float, Optional[float]]:
+    cand = frame_rate
+    if not isinstance(cand, (int, float)) or not np.isfinite(cand) or cand <= 0.0:
+        cfps = context.fps
+        cand = cfps if isinstance(cfps, (int, float)) and np.isfinite(cfps) and cfps > 0.0 else 16.0
+    effective = float(max(1.0, cand))
+    requested = float(frame_rate) if isinstance(frame_rate, (int, float)) and frame_rate > 0.0 else None
+    return effective, requested
+
+
+def _host_frames(context: hm.VideoContext) -> np.ndarray:
+    if context.batch is not None:
+        return context.batch.detach().cpu().numpy()
+    return np.stack([hm._ensure_rgb(f) for f in context.frames], axis=0)
+
+
+def _stabilize_frames(
+    context: hm.VideoContext,
+    framing_mode: str,
+    transform_mode: str,
+    camera_lock: bool,
+    strength: float,
+    smooth: float,
+    keep_fov: float,
+    padding_rgb: Tuple[int, int, int],
+    frame_rate: float,
+    *,
+    ctx: Optional[native.Context] = None,
+    keep_on_device: bool = False,
+    transition_provider=None,
+) -> hm.StabilizationResult:
+    """Positional signature of the reference (flow.py:213-223); keyword-only extras select the GPU
+    context, keep outputs resident in HBM, or inject another estimator (multi-GPU sharding)."""
+    total_frames = len(context.frames)
+    fps_effective, fps_requested = _fps_fields(context, frame_rate)
+    size = (context.width, context.height)
+    rgb_list = [int(c) for c in padding_rgb]
+    flow_backend, flow_fallback_reason = "DIS", None
+
+    if total_frames == 0:  # unreachable through the node (flow.py:242-273)
+        meta = {
+            "frames": 0,
+            "note": "Empty frame sequence; nothing to stabilise.",
+            "transform_mode_requested": transform_mode,
+            "transform_mode_applied": "identity",
+            "camera_lock": camera_lock,
+            "strength": strength,
+            "strength_effective": 0.0,
+            "smooth": smooth,
+            "fps_requested": fps_requested,
+            "fps_effective": fps_effective,
+            "framing": {"mode": framing_mode, "input_size": list(size), "padding_color_rgb": rgb_list},
+            "keep_fov_applied": False,
+            "padding_color_rgb": rgb_list,
+            "flow_backend": flow_backend,
+            "flow_fallback_reason": flow_fallback_reason,
+            "stabilization_warp": hm._build_stabilization_warp_meta(
+                source_size=size, output_size=size, framing_mode=framing_mode, applied_matrices=[]),
+            "estimated_motion": {"per_transition": [], "path": [], "target_path": [], "target_path_effective": []},
+            "padding_fraction_mean": 0.0,
+            "padding_fraction_max": 0.0,
+        }
+        return hm.StabilizationResult([], [], _attach_motion_meta(meta, fps_effective))
+
+    progress_total = max(0, total_frames - 1) + total_frames
+    pbar = ProgressBar(progress_total)
+
+    if total_frames == 1:  # flow.py:289-310
+        meta = {
+            "frames": 1,
+            "note": "Single-frame input; bypassed stabilization.",
+            "transform_mode": transform_mode,
+            "framing_mode": framing_mode,
+            "keep_fov_applied": False,
+            "flow_backend": flow_backend,
+            "flow_fallback_reason": flow_fallback_reason,
+            "stabilization_warp": hm._build_stabilization_warp_meta(
+                source_size=size, output_size=size, framing_mode=framing_mode,
+                applied_matrices=[np.eye(3, dtype=np.float32)]),
+            "fps_requested": fps_requested,
+            "fps_effective": fps_effective,
+        }
+        pbar.update_absolute(progress_total, progress_total)
+        frames_out = _host_frames(context)
+        masks_out = np.zeros((1, context.height, context.width, 1), np.float32)
+        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(meta, fps_effective))
+
+    ctx = ctx or native.default_context()
+    device_frames = context.device_batch(ctx)
+    working_size = hm._working_estimation_size(context.width, context.height)
+    base_mode = transform_mode
+
+    # ---- estimation (F2-F5) -------------------------------------------------
+    if transition_provider is not None:
+        fit_records = transition_provider(ctx, device_frames, working_size, transform_mode)
+    else:
+        fit_records = estimate_transitions(ctx, device_frames, working_size, transform_mode)
+    work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
+    matrices = [hm._rescale_transform_to_full(m, size, working_size) if working_size is not None else m
+                for m in work_mats]
+    delta_params = np.stack([hm._matrix_to_params(m, base_mode) for m in matrices], axis=0)
+    progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
+    check_interrupt()
+
+    # ---- trajectory (F7-F8) --------------------------------------------------
+    strength = float(np.clip(strength, 0.0, 1.0))
+    smooth = float(np.clip(smooth, 0.0, 1.0))
+    path, target_path = ctx.trajectory(delta_params, smooth, fps_effective, strength, bool(camera_lock))
+    if camera_lock:
+        smooth = max(smooth, 0.85)
+    diffs = target_path - path
+
+    keep_fov_clamped = float(np.clip(keep_fov, 0.0, 1.0))
+    keep_fov_applied = framing_mode == "crop" and keep_fov_clamped > 1e-6
+    stabilization_scale = 1.0
+
+    if framing_mode == "crop":
+        if keep_fov_clamped >= 0.9999:  # flow.py:387-429: return the original frames
+            meta = {
+                "frames": total_frames,
+                "note": "keep_fov~=1.0 in crop mode; returning original frames.",
+                "transform_mode_requested": transform_mode,
+                "transform_mode_applied": "identity",
+                "camera_lock": camera_lock,
+                "strength": strength,
+                "strength_effective": 0.0,
+                "smooth": smooth,
+                "fps_requested": fps_requested,
+                "fps_effective": fps_effective,
+                "framing": {
+                    "mode": framing_mode,
+                    "input_size": list(size),
+                    "keep_fov_requested": keep_fov_clamped,
+                    "keep_fov_effective": 1.0,
+                    "min_content_ratio": 1.0,
+                    "padding_color_rgb": rgb_list,
+                    "stabilization_scale": 0.0,
+                },
+                "keep_fov_applied": False,
+                "flow_backend": flow_backend,
+                "flow_fallback_reason": flow_fallback_reason,
+                "stabilization_warp": hm._build_stabilization_warp_meta(
+                    source_size=size, output_size=size, framing_mode=framing_mode,
+                    applied_matrices=[np.eye(3, dtype=np.float32) for _ in range(total_frames)]),
+                "estimated_motion": {
+                    "per_transition": [],
+                    "path": path.tolist(),
+                    "target_path": target_path.tolist(),
+                    "target_path_effective": path.tolist(),
+                },
+                "padding_fraction_mean": 0.0,
+                "padding_fraction_max": 0.0,
+            }
+            pbar.update_absolute(progress_total, progress_total)
+            frames_out = device_frames if keep_on_device else _host_frames(context)
+            masks_out = (ctx.torch.zeros((total_frames, context.height, context.width, 1), device=ctx.device)
+                         if keep_on_device else np.zeros((total_frames, context.height, context.width, 1), np.float32))
+            return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(meta, fps_effective))
+        raise NotImplementedError(
+            "framing_mode='crop' (keep_fov crop solver, stabilizer_utils.py:448-837) is outside the hot path "
+            "built so far; use 'crop_and_pad' or 'expand'.")
+
+    apply_matrices = [hm._params_to_matrix(d, base_mode) for d in diffs]
+    output_size = size
+    mins, maxs = hm._compute_bounding_boxes(apply_matrices, context.width, context.height)
+    framing_meta: Dict[str, Any] = {
+        "mode": framing_mode,
+        "input_size": list(size),
+        "padding_color_rgb": rgb_list,
+        "min_content_ratio": hm._min_content_ratio(mins, maxs, context.width, context.height),
+    }
+    if framing_mode == "crop_and_pad":  # flow.py:500-529
+        x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1]))
+        x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
+        inter_w, inter_h = max(1.0, x1 - x0), max(1.0, y1 - y0)
+        off_x = context.width * 0.5 - (x0 + x1) * 0.5
+        off_y = context.height * 0.5 - (y0 + y1) * 0.5
+        shift = np.array([[1.0, 0.0, off_x], [0.0, 1.0, off_y], [0.0, 0.0, 1.0]], dtype=np.float32)
+        final_matrices = [shift @ m for m in apply_matrices]
+        framing_meta.update({
+            "safe_region_origin": [x0, y0],
+            "safe_region_size": [inter_w, inter_h],
+            "actual_content_ratio": min(inter_w / context.width, inter_h / context.height),
+            "center_offset": [off_x, off_y],
+        })
+    elif framing_mode == "expand":  # flow.py:530-533
+        shift, output_size = hm._prepare_expand_transform(mins, maxs)
+        final_matrices = [shift @ m for m in apply_matrices]
+        framing_meta["expanded_size"] = list(output_size)
+    else:
+        raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
+
+    stabilization_scale = float(np.clip(stabilization_scale, 0.0, 1.0))
+    effective_target_path = path + diffs
+
+    # ---- warp (F13) ------------------------------------------------------------
+    dst, mask, counts = ctx.warp_batch(
+        device_frames, np.stack(final_matrices).astype(np.float32), output_size, interp="bilinear",
+        border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
+    counts_host = counts.cpu().numpy().astype(np.int64)
+    pixels = np.float32(output_size[0] * output_size[1])
+    padded_ratios = [float(np.float32(c) / pixels) for c in counts_host]  # mask.mean() in float32 (flow.py:587)
+    padding_detected = bool((counts_host > 0).any())
+    framing_meta["padding_detected"] = padding_detected
+    progress_done = _replay_progress(pbar, progress_done, total_frames, progress_total)
+    check_interrupt()
+
+    meta = {
+        "frames": total_frames,
+        "transform_mode_requested": transform_mode,
+        "transform_mode_applied": active_mode,
+        "camera_lock": camera_lock,
+        "strength": strength,
+        "strength_effective": strength * stabilization_scale,
+        "smooth": smooth,
+        "fps_requested": fps_requested,
+        "fps_effective": fps_effective,
+        "framing": framing_meta,
+        "keep_fov_applied": keep_fov_applied,
+        "padding_color_rgb": rgb_list,
+        "flow_backend": flow_backend,
+        "flow_fallback_reason": flow_fallback_reason,
+        "stabilization_warp": hm._build_stabilization_warp_meta(
+            source_size=size, output_size=output_size, framing_mode=framing_mode, applied_matrices=final_matrices),
+        "estimated_motion": {
+            "per_transition": [
+                {"index": i, "mode": mode, "confidence": conf, "residual": resid,
+                 "matrix": matrices[i].astype(np.float32).tolist()}
+                for i, (mode, conf, resid) in enumerate(zip(modes_used, confidences, residuals))
+            ],
+            "path": path.tolist(),
+            "target_path": target_path.tolist(),
+            "target_path_effective": effective_target_path.tolist(),
+        },
+        "padding_fraction_mean": float(np.mean(padded_ratios)),
+        "padding_fraction_max": float(np.max(padded_ratios)),
+    }
+    meta = _attach_motion_meta(meta, fps_effective)
+    if keep_on_device:
+        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
+    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)

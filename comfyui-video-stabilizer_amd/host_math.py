@@ -1,0 +1,354 @@
+"""Host-side (fp64 NumPy) pieces of the stabilization path: input adaptation, the parameter space
+used for smoothing, framing geometry and the small JSON helpers.
+
+Mirrors the behaviour of the reference's nodes/stabilizer_utils.py (cited per function); the
+pixel work these helpers used to feed into OpenCV now goes to libvstab (native.py).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, Iterable, List, Literal, Optional, Sequence, Tuple
+
+import numpy as np
+
+try:  # torch is the frame container at the node boundary
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+FramingMode = Literal["crop", "crop_and_pad", "expand"]
+TransformMode = Literal["translation", "similarity", "perspective"]
+
+DEFAULT_ESTIMATION_MAX_SIDE = 960  # stabilizer_utils.py:245
+DEFAULT_PADDING_RGB = (127, 127, 127)  # stabilizer_utils.py:840
+
+
+@dataclass
+class FrameAdapter:
+    """What the first frame looked like on the way in (stabilizer_utils.py:52-60)."""
+
+    dtype: Any
+    channel_first: bool
+    value_range: str
+    origin: str
+    squeeze_last_dim: bool
+
+
+@dataclass
+class VideoContext:
+    """stabilizer_utils.py:63-72 plus an optional batched container for the GPU path."""
+
+    frames: List[Any]
+    adapter: FrameAdapter
+    width: int
+    height: int
+    channels: int
+    fps: Optional[float]
+    template_kind: str
+    template_meta: Dict[str, Any]
+    batch: Any = field(default=None, repr=False)  # torch.Tensor [N,H,W,3] f32 0..1 if already assembled
+
+    def device_batch(self, ctx):
+        """[N,H,W,3] f32 tensor on ctx.device (uploaded once, cached)."""
+        t = self.batch
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(np.stack(self.frames, axis=0), dtype=np.float32))
+        if t.device != ctx.device:
+            t = t.to(ctx.device, non_blocking=True)
+        self.batch = t.contiguous()
+        return self.batch
+
+
+@dataclass
+class StabilizationResult:
+    frames: Any
+    masks: Any
+    meta: Dict[str, Any]
+
+
+# --------------------------------------------------------------------------- input adaptation (F0)
+def _ensure_rgb(frame: np.ndarray) -> np.ndarray:
+    """1 channel -> repeated, >3 channels -> truncated (stabilizer_utils.py:224-233)."""
+    if frame.ndim == 2:
+        frame = frame[..., np.newaxis]
+    c = frame.shape[2]
+    if c == 1:
+        return np.repeat(frame, 3, axis=2)
+    if c > 3:
+        return frame[..., :3]
+    return frame
+
+
+def _to_numpy_frame(frame: Any) -> Tuple[np.ndarray, FrameAdapter]:
+    """One frame -> HxWxC float32 0..1 (stabilizer_utils.py:96-147)."""
+    origin = "numpy"
+    if torch is not None and isinstance(frame, torch.Tensor):
+        origin = "torch"
+        arr = frame.detach().cpu().numpy()
+    else:
+        arr = np.asarray(frame)
+    channel_first = False
+    if arr.ndim == 3 and arr.shape[0] in (1, 3, 4) and arr.shape[0] < arr.shape[-1]:
+        channel_first = True
+        arr = np.moveaxis(arr, 0, -1)
+    elif arr.ndim == 4 and arr.shape[0] == 1:
+        arr = arr[0]
+    squeeze = False
+    if arr.ndim == 2:
+        arr = arr[..., np.newaxis]
+        squeeze = True
+    elif arr.ndim == 3 and arr.shape[2] == 1:
+        squeeze = True
+    dtype = arr.dtype
+    if dtype == np.uint8:
+        arr = arr.astype(np.float32)
+        arr /= 255.0
+        value_range = "0_255"
+    elif bool(arr.size) and float(arr.max()) > 1.5:
+        arr = arr.astype(np.float32)
+        arr /= 255.0
+        value_range = "0_255"
+    else:
+        value_range = "0_1"
+        if dtype != np.float32 or not arr.flags["C_CONTIGUOUS"]:
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+    return arr, FrameAdapter(dtype, channel_first, value_range, origin, squeeze)
+
+
+def _fast_batch(value: Any):
+    """The ComfyUI IMAGE case: a float32 [N,H,W,3] tensor. Range sniffing (>1.5 -> /255, per frame,
+    stabilizer_utils.py:127-131) is done with tensor ops on whatever device the tensor lives on."""
+    if torch is None or not isinstance(value, torch.Tensor):
+        return None
+    if value.ndim != 4 or value.dtype != torch.float32 or value.shape[-1] != 3 or value.shape[0] == 0:
+        return None
+    n, h, w, _ = value.shape
+    if h <= 4:  # tiny heights can trip the reference's per-frame channel-first sniff: take the slow path
+        return None
+    t = value.detach()
+    peaks = t.reshape(n, -1).amax(dim=1)
+    big = peaks > 1.5
+    if bool(big.any()):
+        t = t.clone()
+        t[big] = t[big] / 255.0
+    return t.contiguous(), ("0_255" if bool(big[0]) else "0_1")
+
+
+def _normalize_video_input(value: Any) -> VideoContext:
+    """stabilizer_utils.py:150-197."""
+    if isinstance(value, dict):
+        seq = None
+        for key in ("frames", "images", "video"):
+            if key in value:
+                seq = value[key]
+                break
+        if seq is None:
+            raise ValueError("Video input dictionary must contain 'frames'.")
+        kind = "dict"
+        tmeta = {k: v for k, v in value.items() if k not in ("frames", "images", "video")}
+        fps = tmeta.get("fps")
+    else:
+        seq, kind, tmeta, fps = value, "sequence", {}, None
+
+    fast = _fast_batch(seq)
+    if fast is not None:
+        batch, vrange = fast
+        n, h, w, _ = batch.shape
+        host = batch if batch.device.type == "cpu" else None
+        views = [host[i].numpy() if host is not None else None for i in range(n)]
+        adapter = FrameAdapter(np.dtype(np.float32), False, vrange, "torch", False)
+        return VideoContext(views, adapter, int(w), int(h), 3, fps, kind, tmeta, batch=batch)
+
+    frames: List[np.ndarray] = []
+    first: Optional[FrameAdapter] = None
+    for item in seq:
+        arr, adapter = _to_numpy_frame(item)
+        if first is None:
+            first = adapter
+        elif adapter.channel_first != first.channel_first or adapter.origin != first.origin:
+            raise ValueError("Mixed tensor layouts within the same video sequence are not supported.")
+        frames.append(_ensure_rgb(arr))
+    if not frames:
+        raise ValueError("The input video sequence is empty.")
+    h, w, c = frames[0].shape
+    return VideoContext(frames, first, int(w), int(h), int(c), fps, kind, tmeta)
+
+
+def _reconstruct_video(frames: Any, context: VideoContext) -> Any:
+    """New CPU float32 BHWC tensor, dict inputs get a dict back (stabilizer_utils.py:200-221)."""
+    if torch is not None and isinstance(frames, torch.Tensor):
+        out = frames if frames.shape[0] else torch.zeros((1, context.height, context.width, 3), dtype=torch.float32)
+        out = out.to(dtype=torch.float32).cpu().contiguous()
+    else:
+        if isinstance(frames, np.ndarray) and frames.ndim == 4:
+            stacked = frames if frames.shape[0] else np.zeros((1, context.height, context.width, 3), np.float32)
+        else:
+            items = list(frames)
+            stacked = np.stack(items, axis=0) if items else np.zeros((1, context.height, context.width, 3), np.float32)
+        stacked = np.ascontiguousarray(stacked, dtype=np.float32)
+        out = torch.from_numpy(stacked) if torch is not None else stacked
+    if context.template_kind == "dict":
+        payload = dict(context.template_meta)
+        payload["frames"] = out
+        return payload
+    return out
+
+
+def _convert_masks_for_output(masks: Any) -> Any:
+    """(N,h,w,1)|(N,h,w) -> (N,h,w) float32 (stabilizer_utils.py:1055-1077)."""
+    if torch is not None and isinstance(masks, torch.Tensor):
+        if masks.shape[0] == 0:
+            return torch.zeros((1, 1, 1), dtype=torch.float32)
+        m = masks[..., 0] if masks.ndim == 4 else masks
+        return m.to(dtype=torch.float32).cpu().contiguous()
+    if isinstance(masks, np.ndarray) and masks.ndim in (3, 4):
+        stacked = np.zeros((1, 1, 1), np.float32) if not masks.shape[0] else (masks[..., 0] if masks.ndim == 4 else masks)
+    else:
+        planes = [(m[..., 0] if m.ndim == 3 else m).astype(np.float32) for m in masks]
+        stacked = np.stack(planes, axis=0) if planes else np.zeros((1, 1, 1), np.float32)
+    stacked = np.ascontiguousarray(stacked, dtype=np.float32)
+    return torch.from_numpy(stacked) if torch is not None else stacked
+
+
+# --------------------------------------------------------------------------- estimation geometry (F1, F6)
+def _working_estimation_size(width: int, height: int, max_side: int = DEFAULT_ESTIMATION_MAX_SIDE):
+    """Long side capped to 960 px, None when already small enough (stabilizer_utils.py:248-268)."""
+    longest = max(int(width), int(height))
+    if longest <= max_side:
+        return None
+    scale = max_side / float(longest)
+    sw = max(1, int(round(width * scale)))
+    sh = max(1, int(round(height * scale)))
+    if sw >= width or sh >= height:
+        return None
+    return sw, sh
+
+
+def _rescale_transform_to_full(matrix: np.ndarray, source_size, working_size) -> np.ndarray:
+    """S^-1 @ M @ S in fp64, stored as float32 (stabilizer_utils.py:279-297)."""
+    sx = working_size[0] / float(source_size[0])
+    sy = working_size[1] / float(source_size[1])
+    down = np.array([[sx, 0.0, 0.0], [0.0, sy, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
+    up = np.array([[1.0 / sx, 0.0, 0.0], [0.0, 1.0 / sy, 0.0], [0.0, 0.0, 1.0]], dtype=np.float64)
+    return (up @ matrix.astype(np.float64) @ down).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- parameter space (F6, F9)
+def _matrix_to_params(matrix: np.ndarray, base_mode: str) -> np.ndarray:
+    """stabilizer_utils.py:300-324."""
+    if base_mode == "translation":
+        return np.array([matrix[0, 2], matrix[1, 2]], dtype=np.float64)
+    if base_mode == "similarity":
+        a, c = matrix[0, 0], matrix[1, 0]
+        scale = math.sqrt(max(a * a + c * c, 1e-10))
+        return np.array([matrix[0, 2], matrix[1, 2], math.atan2(c, a), math.log(scale)], dtype=np.float64)
+    m = matrix
+    return np.array([m[0, 0] - 1.0, m[0, 1], m[0, 2], m[1, 0], m[1, 1] - 1.0, m[1, 2], m[2, 0], m[2, 1]],
+                    dtype=np.float64)
+
+
+def _params_to_matrix(params: np.ndarray, base_mode: str) -> np.ndarray:
+    """stabilizer_utils.py:327-358 (float32 result)."""
+    if base_mode == "translation":
+        return np.array([[1.0, 0.0, params[0]], [0.0, 1.0, params[1]], [0.0, 0.0, 1.0]], dtype=np.float32)
+    if base_mode == "similarity":
+        tx, ty, theta, log_scale = params
+        s = math.exp(log_scale)
+        ct, st = math.cos(theta), math.sin(theta)
+        return np.array([[s * ct, -s * st, tx], [s * st, s * ct, ty], [0.0, 0.0, 1.0]], dtype=np.float32)
+    p = params
+    return np.array([[p[0] + 1.0, p[1], p[2]], [p[3], p[4] + 1.0, p[5]], [p[6], p[7], 1.0]], dtype=np.float32)
+
+
+def smoothing_window(smooth: float, fps: float) -> int:
+    """Odd box-filter length derived from fps (stabilizer_utils.py:367-374)."""
+    fps = float(max(1.0, fps))
+    seconds = 3.0 / 16.0 + float(np.clip(smooth, 0.0, 1.0)) * (13.0 / 16.0 - 3.0 / 16.0)
+    window = max(3, int(round(seconds * fps)))
+    return window + 1 if window % 2 == 0 else window
+
+
+# --------------------------------------------------------------------------- framing geometry (F10-F12)
+def _compute_bounding_boxes(matrices: Sequence[np.ndarray], width: int, height: int):
+    """Per-frame min/max of the four warped corners (stabilizer_utils.py:1010-1034)."""
+    corners = np.array([[0.0, 0.0, 1.0], [width, 0.0, 1.0], [0.0, height, 1.0], [width, height, 1.0]], dtype=np.float64).T
+    mins, maxs = [], []
+    for m in matrices:
+        pts = m @ corners
+        pts /= pts[2, :]
+        mins.append([pts[0].min(), pts[1].min()])
+        maxs.append([pts[0].max(), pts[1].max()])
+    return np.array(mins), np.array(maxs)
+
+
+def _min_content_ratio(mins: np.ndarray, maxs: np.ndarray, width: int, height: int) -> float:
+    """stabilizer_utils.py:1037-1052."""
+    iw = max(0.0, np.min(maxs[:, 0]) - np.max(mins[:, 0]))
+    ih = max(0.0, np.min(maxs[:, 1]) - np.max(mins[:, 1]))
+    if iw <= 0.0 or ih <= 0.0:
+        return 1e-6
+    return max(1e-6, min(iw / width, ih / height))
+
+
+def _prepare_expand_transform(mins: np.ndarray, maxs: np.ndarray):
+    """Translation + canvas size that keep every frame inside (stabilizer_utils.py:386-406)."""
+    x_min, y_min = float(np.min(mins[:, 0])), float(np.min(mins[:, 1]))
+    x_max, y_max = float(np.max(maxs[:, 0])), float(np.max(maxs[:, 1]))
+    out_w = int(math.ceil(x_max - x_min))
+    out_h = int(math.ceil(y_max - y_min))
+    shift = np.array([[1.0, 0.0, -x_min], [0.0, 1.0, -y_min], [0.0, 0.0, 1.0]], dtype=np.float32)
+    return shift, (max(out_w, 1), max(out_h, 1))
+
+
+# --------------------------------------------------------------------------- JSON helpers
+def _parse_padding_color(value) -> Tuple[int, int, int]:
+    """'#RRGGBB' | '#RGB' | 'r,g,b' | 0xRRGGBB -> (r,g,b) (stabilizer_utils.py:843-873)."""
+    if isinstance(value, str):
+        text = value.strip()
+        if "," in text or "/" in text:
+            try:
+                parts = [int(p) for p in text.replace("/", ",").replace(" ", ",").split(",") if p != ""]
+                if len(parts) == 1:
+                    parts = parts * 3
+                if len(parts) != 3:
+                    return DEFAULT_PADDING_RGB
+                return tuple(int(np.clip(c, 0, 255)) for c in parts)
+            except (TypeError, ValueError):
+                return DEFAULT_PADDING_RGB
+        digits = text[1:] if text.startswith("#") else text
+        if len(digits) == 3:
+            digits = "".join(ch * 2 for ch in digits)
+        if len(digits) != 6:
+            return DEFAULT_PADDING_RGB
+        try:
+            packed = int(digits, 16)
+        except (TypeError, ValueError):
+            return DEFAULT_PADDING_RGB
+    else:
+        try:
+            packed = int(value)
+        except (TypeError, ValueError):
+            return DEFAULT_PADDING_RGB
+    packed = int(np.clip(packed, 0, 0xFFFFFF))
+    return (packed >> 16) & 0xFF, (packed >> 8) & 0xFF, packed & 0xFF
+
+
+def border_value(padding_rgb: Sequence[int]) -> np.ndarray:
+    """rgb/255 evaluated in float32, as cv2 receives it (flow.py:547-548, motion_apply.py:70-72)."""
+    return np.array(padding_rgb, dtype=np.float32) / 255.0
+
+
+def _build_stabilization_warp_meta(*, source_size, output_size, framing_mode, applied_matrices) -> Dict[str, Any]:
+    """stabilizer_utils.py:876-896."""
+    return {
+        "source_size": [int(source_size[0]), int(source_size[1])],
+        "output_size": [int(output_size[0]), int(output_size[1])],
+        "framing_mode": framing_mode,
+        "matrix_convention": "source_to_stabilized",
+        "per_frame": [
+            {"index": int(i), "applied_matrix": np.asarray(m, dtype=np.float32).tolist()}
+            for i, m in enumerate(applied_matrices)
+        ],
+    }

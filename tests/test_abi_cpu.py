@@ -1,0 +1,127 @@
+"""CPU tests: libvstab.so loads and exports every symbol include/vstab.h declares; the oracle builds;
+oracle known-answer checks that need no GPU; node schema (KA11)."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def header_symbols():
+    text = (ROOT / "include" / "vstab.h").read_text()
+    return sorted(set(re.findall(r"\b(vstab_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from vstab_amd import native
+
+    assert native.LIB_PATH.exists(), "libvstab.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(str(native.LIB_PATH))
+    declared = header_symbols()
+    assert len(declared) >= 13
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vstab.h but not exported"
+    assert set(native.EXPORTED_SYMBOLS) == set(declared)
+    lib.vstab_abi_version.restype = ctypes.c_int
+    assert lib.vstab_abi_version() == 1
+
+
+def test_product_fails_loudly_without_gpu(pkg):
+    import torch
+
+    from vstab_amd import native
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.VstabError):
+        native.default_context()
+
+
+def test_product_does_not_import_oracle(pkg):
+    """The oracle is a checker only: nothing in the package (except the smoke self-check, which is
+    allowed to compare against it) may import, include or load anything under oracle/."""
+    pkg_dir = ROOT / "comfyui-video-stabilizer_amd"
+    for path in pkg_dir.glob("*.py"):
+        if path.name == "selfcheck.py":
+            continue
+        text = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+[^\n]*oracle", text, re.M), path
+        assert "libvstab_oracle" not in text and "oracle/" not in text, path
+    for path in (pkg_dir / "csrc").glob("*.hip"):
+        assert not re.search(r"#include[^\n]*(oracle|vo_)", path.read_text()), path
+
+
+def test_node_schema_sockets(pkg):
+    """KA11 (scripts/check_node_schema.py:28-64): ordered socket names of both nodes."""
+    from vstab_amd import nodes
+
+    s = nodes.VideoStabilizerFlow.define_schema()
+    assert s.node_id == "video_stabilizer_flow" and s.display_name == "Video Stabilizer Flow"
+    assert [i.id for i in s.inputs] == ["frames", "frame_rate", "framing_mode", "transform_mode", "camera_lock",
+                                        "strength", "smooth", "keep_fov", "padding_color"]
+    assert [o.id for o in s.outputs] == ["frames_stabilized", "padding_mask", "meta"]
+    s = nodes.VideoStabilizerMotionApply.define_schema()
+    assert s.node_id == "video_stabilizer_motion_apply" and s.display_name == "Video Stabilizer Motion Apply"
+    assert [i.id for i in s.inputs] == ["frames", "motion_meta", "framing_mode", "interpolation", "padding_color",
+                                        "motion_blur", "motion_blur_quality"]
+    assert [o.id for o in s.outputs] == ["frames", "padding_mask", "meta"]
+    assert nodes.BLUR_QUALITY_SAMPLES == {"Draft": 5, "Standard": 9, "High": 17, "Ultra": 33}
+
+
+# ---------------------------------------------------------------- oracle known answers (no GPU)
+def test_oracle_identity_warp_is_passthrough(oracle):
+    """KA1: identity -> output == input, coverage all ones."""
+    from tests.util import synth_frames
+
+    f = synth_frames(2, 24, 32)
+    eye = np.tile(np.eye(3, dtype=np.float32), (2, 1, 1))
+    for interp in ("bilinear", "bicubic"):
+        dst, mask, cnt = oracle.warp_clip(f, eye, (32, 24), interp=interp, border=(0.5, 0.5, 0.5))
+        assert np.array_equal(dst, f) and mask.max() == 0 and cnt.sum() == 0
+
+
+def test_oracle_integer_shift_and_tables(oracle):
+    from tests.util import synth_frames
+
+    f = synth_frames(1, 24, 32)
+    m = np.eye(3, dtype=np.float32)[None].copy()
+    m[0, 0, 2], m[0, 1, 2] = 3.0, 2.0
+    dst, mask, cnt = oracle.warp_clip(f, m, (32, 24), border=(0.25, 0.5, 0.75))
+    assert np.array_equal(dst[0, 2:, 3:], f[0, :-2, :-3])
+    assert np.allclose(dst[0, 0, 0], (0.25, 0.5, 0.75)) and mask[0, :2].min() == 1 and mask[0, 2:, 3:].max() == 0
+    assert cnt[0] == 24 * 32 - 22 * 29
+    lin, cub = oracle.interp_tables()
+    assert np.allclose(lin.sum(1), 1) and np.allclose(cub.sum(1), 1, atol=1e-6)
+    assert np.allclose(cub[0], (0, 1, 0, 0)) and cub[16, 0] == pytest.approx(-0.09375)
+    inv = oracle.invert3x3([[2, 0, 1], [0, 4, -2], [0, 0, 1]])
+    assert np.allclose(inv @ np.array([[2, 0, 1], [0, 4, -2], [0, 0, 1.0]]), np.eye(3))
+    assert np.array_equal(oracle.linspace(0.0, 0.5, 17), np.linspace(0.0, 0.5, 17))
+
+
+def test_oracle_area_resize_and_gray(oracle):
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    half = oracle.resize_area_u8(g, (32, 20))
+    man = ((g[0::2, 0::2].astype(int) + g[0::2, 1::2] + g[1::2, 0::2] + g[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(half, man)
+    const = np.full((45, 73), 77, np.uint8)
+    assert np.all(oracle.resize_area_u8(const, (31, 19)) == 77)
+    rgb = np.full((4, 8, 3), 0.5, np.float32)
+    assert np.all(oracle.rgb2gray_u8(rgb) == 127)  # truncation, not rounding (127.5 -> 127)
+
+
+def test_oracle_dis_and_fit_recover_known_motion(oracle):
+    from tests.test_dis_gpu import moving_clip
+
+    gray, params = moving_clip(2, 135, 240, seed=3)
+    flow = oracle.dis_flow_clip(gray)[0]
+    tx, ty = params[1][0], params[1][1]
+    assert abs(np.median(flow[..., 0]) - tx) < 0.1 and abs(np.median(flow[..., 1]) - ty) < 0.1
+    m, mode, conf, resid = oracle.fit_from_flow(flow, 8, "similarity")
+    assert mode == "similarity" and conf > 0.8 and resid < 0.5
+    assert abs(m[0, 2] - tx) < 0.5 and abs(m[1, 2] - ty) < 0.5 and abs(m[0, 0] - 1) < 0.01
+    assert oracle.dis_coarsest_scale(540, 960) == 5 and oracle.dis_coarsest_scale(480, 854) == 5

@@ -1,0 +1,191 @@
+"""CPU tests: the host-side helpers and the motion_meta contract against golden vectors captured from
+the reference's own NumPy helpers (tests/golden/make_golden.py, run in the build container)."""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_helpers.json").read_text())
+
+
+def nd(x):
+    return np.array(x["__nd__"], dtype=x["dtype"]).reshape(x["shape"])
+
+
+def unwrap(x):
+    if isinstance(x, dict) and "__nd__" in x:
+        return nd(x)
+    if isinstance(x, dict):
+        return {k: unwrap(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [unwrap(v) for v in x]
+    return x
+
+
+@pytest.fixture(scope="module")
+def hm(pkg):
+    from vstab_amd import host_math
+
+    return host_math
+
+
+@pytest.fixture(scope="module")
+def mv(pkg):
+    from vstab_amd import meta_v2
+
+    return meta_v2
+
+
+def test_working_size(hm):
+    for case in GOLD["working_size"]:
+        out = hm._working_estimation_size(*case["in"])
+        assert (list(out) if out is not None else None) == case["out"]
+
+
+def test_params_roundtrip_and_rescale(hm):
+    for case in GOLD["params"]:
+        m = nd(case["matrix"])
+        p = hm._matrix_to_params(m, case["mode"])
+        assert p.dtype == np.float64 and np.array_equal(p, nd(case["params"]))
+        back = hm._params_to_matrix(p, case["mode"])
+        assert back.dtype == np.float32 and np.array_equal(back, nd(case["back"]))
+        assert np.array_equal(hm._rescale_transform_to_full(m, (1920, 1080), (960, 540)), nd(case["rescaled"]))
+        assert np.array_equal(hm._rescale_transform_to_full(m, (3840, 2160), (960, 540)), nd(case["rescaled_4k"]))
+
+
+def test_smoothing_window_matches_reference_outputs(hm):
+    """The window length is implied by the reference outputs: a constant-1 path stays 1, and the
+    number of distinct rows affected near an impulse equals the window."""
+    assert [hm.smoothing_window(s, 16.0) for s in (0.0, 0.5, 1.0)] == [3, 9, 13]
+    assert [hm.smoothing_window(s, 24.0) for s in (0.0, 0.5, 1.0)] == [5, 13, 21]
+    assert [hm.smoothing_window(s, 30.0) for s in (0.0, 0.5, 1.0)] == [7, 15, 25]
+    assert [hm.smoothing_window(s, 60.0) for s in (0.0, 0.5, 1.0)] == [11, 31, 49]
+
+
+def test_bbox_expand_ratio(hm):
+    shake = GOLD["shake_small"]
+    mats = [np.asarray(e["matrix"], dtype=np.float64) for e in shake["per_frame"]]
+    mins, maxs = hm._compute_bounding_boxes(mats, 192, 108)
+    b = GOLD["bbox"]
+    assert np.array_equal(mins, nd(b["mins"])) and np.array_equal(maxs, nd(b["maxs"]))
+    assert hm._min_content_ratio(mins, maxs, 192, 108) == b["ratio"]
+    t, size = hm._prepare_expand_transform(mins, maxs)
+    assert np.array_equal(t, nd(b["expand_matrix"])) and list(size) == b["expand_size"]
+    lit = GOLD["expand_literal"]
+    t, size = hm._prepare_expand_transform(nd(lit["mins"]), nd(lit["maxs"]))
+    assert np.array_equal(t, nd(lit["matrix"])) and list(size) == lit["size"]
+    assert hm._min_content_ratio(nd(lit["mins"]), nd(lit["maxs"]), 73, 45) == lit["ratio"]
+
+
+def test_expand_matrices_and_blur_samples(pkg, hm):
+    from vstab_amd import apply_pipeline as ap
+
+    shake = GOLD["shake_small"]
+    mats = [np.asarray(e["matrix"], dtype=np.float64) for e in shake["per_frame"]]
+    em, size = ap._expand_matrices(mats, (192, 108))
+    assert np.array_equal(np.stack(em), nd(GOLD["expand_matrices"]["matrices"]))
+    assert list(size) == GOLD["expand_matrices"]["size"]
+    for case in GOLD["blur_samples"]:
+        got = np.stack(ap._blurred_matrix_samples(mats, case["idx"], case["blur"], case["samples"]))
+        assert np.array_equal(got, nd(case["out"]))
+    assert np.array_equal(np.stack(ap._blurred_matrix_samples(mats[:1], 0, 0.5, 9)), nd(GOLD["blur_single"]))
+
+
+def test_padding_color(hm):
+    for case in GOLD["padding_color"]:
+        assert list(hm._parse_padding_color(case["in"])) == case["out"], case["in"]
+    assert hm.border_value((127, 127, 127))[0] == np.float32(0.49803921580314636)
+
+
+def test_warp_meta_and_motion_meta_blocks(hm, mv):
+    shake = GOLD["shake_small"]
+    mats = [np.asarray(e["matrix"], dtype=np.float64).astype(np.float32) for e in shake["per_frame"]][:3]
+    warp = hm._build_stabilization_warp_meta(source_size=(192, 108), output_size=(200, 120), framing_mode="expand",
+                                             applied_matrices=mats)
+    assert warp == GOLD["warp_meta"]
+    assert mv.applied_motion_meta_from_stabilization_warp(warp, fps=16.0, source="estimated_flow") == GOLD["mm_applied"]
+    assert mv.motion_meta_from_stabilization_warp(warp, fps=24.0, source="legacy_stabilization") == GOLD["mm_inverse"]
+    r = mv.resolve_motion_meta({"stabilization_warp": warp})
+    g = GOLD["mm_resolve_legacy"]
+    assert (r.source, r.frame_count, r.fps, list(r.input_size), list(r.output_size)) == (
+        g["source"], g["frame_count"], g["fps"], g["input_size"], g["output_size"])
+    assert np.array_equal(np.stack([t.matrix for t in r.per_frame]), nd(g["matrices"]))
+    # generated shake blocks validate (generator present)
+    mv.validate_motion_meta(shake)
+
+
+def test_motion_meta_error_messages(mv):
+    ok = GOLD["mm_ok"]
+
+    def mutate(**kw):
+        b = json.loads(json.dumps(ok))
+        b.update(kw)
+        return b
+
+    nan = float("nan")
+    calls = {
+        "not_dict": lambda: mv.validate_motion_meta([]),
+        "version": lambda: mv.validate_motion_meta(mutate(version=1)),
+        "convention": lambda: mv.validate_motion_meta(mutate(matrix_convention="x")),
+        "source": lambda: mv.validate_motion_meta(mutate(source="")),
+        "frame_count_type": lambda: mv.validate_motion_meta(mutate(frame_count="abc")),
+        "frame_count_neg": lambda: mv.validate_motion_meta(mutate(frame_count=-1)),
+        "fps": lambda: mv.validate_motion_meta(mutate(fps=0)),
+        "fps_type": lambda: mv.validate_motion_meta(mutate(fps="q")),
+        "input_size": lambda: mv.validate_motion_meta(mutate(input_size=[1])),
+        "input_size_neg": lambda: mv.validate_motion_meta(mutate(input_size=[0, 4])),
+        "input_size_type": lambda: mv.validate_motion_meta(mutate(output_size=["a", 4])),
+        "per_frame_type": lambda: mv.validate_motion_meta(mutate(per_frame={})),
+        "count_mismatch": lambda: mv.validate_motion_meta(mutate(frame_count=3)),
+        "entry_type": lambda: mv.validate_motion_meta(mutate(per_frame=[1, 2])),
+        "entry_index": lambda: mv.validate_motion_meta(mutate(per_frame=[ok["per_frame"][1], ok["per_frame"][0]])),
+        "entry_missing": lambda: mv.validate_motion_meta(mutate(per_frame=[{"index": 0}, ok["per_frame"][1]])),
+        "entry_shape": lambda: mv.validate_motion_meta(mutate(per_frame=[{"index": 0, "matrix": [[1, 0], [0, 1]]}, ok["per_frame"][1]])),
+        "entry_nan": lambda: mv.validate_motion_meta(mutate(per_frame=[{"index": 0, "matrix": [[nan, 0, 0], [0, 1, 0], [0, 0, 1]]}, ok["per_frame"][1]])),
+        "entry_singular": lambda: mv.validate_motion_meta(mutate(per_frame=[{"index": 0, "matrix": [[0, 0, 0]] * 3}, ok["per_frame"][1]])),
+        "shake_generator": lambda: mv.validate_motion_meta(mutate(source="generated_shake")),
+        "resolve_not_dict": lambda: mv.resolve_motion_meta(3),
+        "resolve_empty": lambda: mv.resolve_motion_meta({}),
+        "warp_not_dict": lambda: mv.motion_meta_from_stabilization_warp(3, 16.0, "x"),
+        "warp_convention": lambda: mv.applied_motion_meta_from_stabilization_warp({"matrix_convention": "q"}, 16.0, "x"),
+        "warp_per_frame": lambda: mv.applied_motion_meta_from_stabilization_warp(
+            {"matrix_convention": "source_to_stabilized", "source_size": [4, 4], "output_size": [4, 4], "per_frame": 3}, 16.0, "x"),
+    }
+    assert set(calls) == set(GOLD["mm_errors"])
+    for name, fn in calls.items():
+        expected = GOLD["mm_errors"][name]
+        assert expected is not None, name
+        with pytest.raises(ValueError) as info:
+            fn()
+        assert str(info.value) == expected["message"], name
+    assert mv.build_motion_meta_v2(source="manual", frame_count=2, fps=16.0, input_size=(8, 6), output_size=(8, 6),
+                                   matrices=[np.eye(3), np.eye(3)]) == ok
+
+
+def test_normalize_video_input_layouts(hm):
+    import torch
+
+    for name, case in GOLD["normalize"].items():
+        value = unwrap(case["input"])
+        c = hm._normalize_video_input(value)
+        assert (c.width, c.height, c.channels, c.fps, c.template_kind) == (
+            case["width"], case["height"], case["channels"], case["fps"], case["template_kind"]), name
+        frames = np.stack([np.asarray(f) for f in c.frames])
+        assert frames.dtype == np.float32 and np.array_equal(frames, nd(case["frames"])), name
+        rec = hm._reconstruct_video(c.frames, c)
+        payload = rec["frames"] if isinstance(rec, dict) else rec
+        assert isinstance(payload, torch.Tensor) and payload.dtype == torch.float32
+        assert np.array_equal(payload.numpy(), nd(case["frames"])), name
+    # the ComfyUI IMAGE fast path (float32 BHWC tensor) gives the same frames, incl. per-frame /255 sniffing
+    batch = nd(GOLD["normalize"]["batch"]["frames"])
+    t = torch.from_numpy(np.tile(batch, (1, 2, 2, 1)).copy())
+    t[1] *= 255.0
+    c = hm._normalize_video_input(t)
+    ref = hm._normalize_video_input([f for f in t.numpy()])
+    assert c.batch is not None and np.array_equal(c.batch.numpy(), np.stack(ref.frames))
+    for name, err in GOLD["normalize_errors"].items():
+        with pytest.raises(ValueError) as info:
+            hm._normalize_video_input([] if name == "empty" else {"x": 1})
+        assert str(info.value) == err["message"]

@@ -1,0 +1,226 @@
+"""End-to-end GPU tests of the two nodes through the C ABI: reference-pinned properties (KA1-KA12 of
+SURVEY 8c) and parity of every stage against the oracle on a clip with known camera motion."""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import synth_frames
+
+pytestmark = pytest.mark.gpu
+BORDER = np.array([127, 127, 127], np.float32) / 255.0
+
+
+def ramp_frames(count, width=32, height=24):
+    """Analytic ramp frames in the spirit of check_motion_meta.py:31-40 (own construction)."""
+    yy, xx = np.mgrid[0:height, 0:width]
+    out = np.zeros((count, height, width, 3), np.float32)
+    for i in range(count):
+        out[i, ..., 0] = (xx + i) / max(width + count - 1, 1)
+        out[i, ..., 1] = yy / max(height - 1, 1)
+        out[i, ..., 2] = ((xx + yy + i) % 7) / 6.0
+    return out
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    from vstab_amd import apply_pipeline, flow_pipeline, host_math, meta_v2, nodes
+
+    class A:
+        pass
+
+    a = A()
+    a.ap, a.fp, a.hm, a.mv, a.nodes = apply_pipeline, flow_pipeline, host_math, meta_v2, nodes
+    return a
+
+
+def block(api, mats, size, out_size=None, n=None):
+    return {"motion_meta": api.mv.build_motion_meta_v2(source="manual", frame_count=len(mats), fps=16.0, input_size=size,
+                                                        output_size=out_size or size, matrices=mats)}
+
+
+def shift(tx, ty):
+    return np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float64)
+
+
+def test_identity_apply_and_blur_zero_path(api, ctx):
+    """KA1: identity == input within 1e-6, mask all 0, blur=0 bit-identical to the plain path."""
+    frames = ramp_frames(3)
+    c = api.hm._normalize_video_input(frames)
+    meta = block(api, [np.eye(3)] * 3, (32, 24))
+    base = api.ap.apply_motion(c, meta, (127, 127, 127))
+    assert np.max(np.abs(base.frames - frames)) <= 1e-6 and base.masks.max() == 0.0 and base.masks.shape == (3, 24, 32, 1)
+    again = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), motion_blur=0.0, motion_blur_samples=17)
+    assert np.array_equal(again.frames, base.frames) and np.array_equal(again.masks, base.masks)
+
+
+def test_expand_enlarges_canvas(api, ctx):
+    """KA2: I, T(6,-4), T(-6,4) on 32x24 -> 44x32 and meta says expand."""
+    frames = ramp_frames(3)
+    meta = block(api, [np.eye(3), shift(6, -4), shift(-6, 4)], (32, 24))
+    r = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="expand")
+    assert r.frames.shape == (3, 32, 44, 3)
+    assert r.meta["motion_apply"]["framing_mode"] == "expand" and r.meta["motion_apply"]["output_size"] == [44, 32]
+
+
+def test_blur_deterministic_and_ticks(api, ctx):
+    """KA3 + KA4: blur is deterministic, meta records it, progress ticks = N*S (+N for crop)."""
+    frames = ramp_frames(4)
+    meta = block(api, [shift(0.5 * i, -0.25 * i) for i in range(4)], (32, 24))
+    ticks = []
+    r1 = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), motion_blur=0.5, motion_blur_samples=5,
+                             progress_callback=lambda: ticks.append(1))
+    r2 = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), motion_blur=0.5, motion_blur_samples=5)
+    assert np.array_equal(r1.frames, r2.frames) and r1.meta["motion_apply"]["motion_blur"] == 0.5
+    assert r1.meta["motion_apply"]["motion_blur_samples"] == 5 and len(ticks) == 4 * 5
+    ticks.clear()
+    api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop", motion_blur=0.5,
+                        motion_blur_samples=5, progress_callback=lambda: ticks.append(1))
+    assert len(ticks) == 4 + 4 * 5
+    # through the node: Ultra -> 33 samples
+    import torch
+
+    out = api.nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(frames), meta, "crop_and_pad", "bilinear", "#7F7F7F", 0.5, "Ultra")
+    assert out[2]["motion_apply"]["motion_blur_samples"] == 33 and out[2]["motion_apply"]["motion_blur_quality"] == "Ultra"
+    out = api.nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(frames), meta, "crop_and_pad", "bilinear", "#7F7F7F", 0.5, "bogus")
+    assert out[2]["motion_apply"]["motion_blur_quality"] == "Standard"
+
+
+def test_crop_fallback_and_crop_success(api, ctx):
+    """KA5: a 60 px shift on 32x24 leaves no common region -> framing_fallback == crop_and_pad."""
+    frames = ramp_frames(2)
+    meta = block(api, [np.eye(3), shift(60, 0)], (32, 24))
+    r = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop")
+    assert r.meta["framing_fallback"] == "crop_and_pad" and r.meta["motion_apply"]["framing_mode"] == "crop_and_pad"
+    meta = block(api, [np.eye(3), shift(2, 1)], (32, 24))
+    r = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop")
+    assert "framing_fallback" not in r.meta and r.masks.max() == 0.0 and r.meta["motion_apply"]["framing_mode"] == "crop"
+
+
+def test_legacy_warp_resolution_and_context_selection(api, ctx):
+    """KA6: stabilization_warp 80x50 -> 96x60: direct apply gives 60x96, inverse (context-selected) 50x80."""
+    m = np.array([[1.2, 0, 0], [0, 1.2, 0], [0, 0, 1]], np.float32)
+    warp = api.hm._build_stabilization_warp_meta(source_size=(80, 50), output_size=(96, 60), framing_mode="expand", applied_matrices=[m, m])
+    meta = {"stabilization_warp": warp, "motion_meta": api.mv.applied_motion_meta_from_stabilization_warp(warp, 16.0, "estimated_flow")}
+    direct = api.ap.apply_motion(api.hm._normalize_video_input(synth_frames(2, 50, 80)), meta, (0, 0, 0))
+    assert direct.frames.shape == (2, 60, 96, 3) and direct.meta["motion_apply"]["source"] == "estimated_flow"
+    inverse = api.ap.apply_motion(api.hm._normalize_video_input(synth_frames(2, 60, 96)), meta, (0, 0, 0))
+    assert inverse.frames.shape == (2, 50, 80, 3) and inverse.meta["motion_apply"]["source"] == "legacy_stabilization"
+    r = api.mv.resolve_motion_meta({"stabilization_warp": warp})
+    assert r.input_size == (96, 60) and r.output_size == (80, 50) and np.allclose(r.per_frame[0].matrix, np.linalg.inv(m.astype(np.float64)))
+
+
+def test_error_texts(api, ctx):
+    """KA12 + A2: ValueError texts for missing meta, size and frame-count mismatches, bad enums."""
+    frames = ramp_frames(2)
+    c = api.hm._normalize_video_input(frames)
+    with pytest.raises(ValueError, match="meta must contain motion_meta or stabilization_warp."):
+        api.ap.apply_motion(c, {}, (0, 0, 0))
+    meta = block(api, [np.eye(3)] * 2, (40, 24))
+    with pytest.raises(ValueError, match=r"Input frames must match motion_meta.input_size \(40, 24\), got \(32, 24\)\."):
+        api.ap.apply_motion(c, meta, (0, 0, 0))
+    meta = block(api, [np.eye(3)] * 3, (32, 24))
+    with pytest.raises(ValueError, match=r"Frame count mismatch: got 2 frame\(s\), metadata has 3 matrix entry/entries\."):
+        api.ap.apply_motion(c, meta, (0, 0, 0))
+    meta = block(api, [np.eye(3)] * 2, (32, 24))
+    with pytest.raises(ValueError, match="Unsupported interpolation 'nearest'; expected 'bilinear' or 'bicubic'."):
+        api.ap.apply_motion(c, meta, (0, 0, 0), interpolation="nearest")
+    with pytest.raises(ValueError, match="Unsupported framing_mode 'zoom'; expected 'crop_and_pad', 'crop', or 'expand'."):
+        api.ap.apply_motion(c, meta, (0, 0, 0), framing_mode="zoom")
+    r = api.ap.apply_motion(c, meta, (0, 0, 0), framing_mode="pad")
+    assert r.meta["motion_apply"]["framing_mode"] == "crop_and_pad"
+
+
+FLOW_META_KEYS = ["frames", "transform_mode_requested", "transform_mode_applied", "camera_lock", "strength", "strength_effective",
+                  "smooth", "fps_requested", "fps_effective", "framing", "keep_fov_applied", "padding_color_rgb", "flow_backend",
+                  "flow_fallback_reason", "stabilization_warp", "estimated_motion", "padding_fraction_mean", "padding_fraction_max",
+                  "motion_meta"]
+
+
+@pytest.mark.parametrize("size,mode,framing", [((480, 270), "similarity", "crop_and_pad"), ((480, 270), "translation", "expand"),
+                                               ((1920, 1080), "similarity", "crop_and_pad")])
+def test_flow_pipeline_against_oracle(api, ctx, oracle, size, mode, framing):
+    """Every stage of the Flow node vs the oracle on a clip with known motion; KA7 replay bit-identity;
+    the meta key set / list lengths / types of SURVEY 8a "Meta detail"."""
+    from tests.test_dis_gpu import moving_clip
+
+    w, h = size
+    n = 7 if w <= 960 else 4
+    gray_full, params = moving_clip(n, h, w, seed=w)
+    frames = np.repeat(gray_full[..., None].astype(np.float32) / 255.0, 3, axis=-1)
+    frames[..., 1] *= 0.9
+    frames = np.ascontiguousarray(frames)
+    c = api.hm._normalize_video_input(frames)
+    res = api.fp._stabilize_frames(c, framing, mode, False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+    meta = res.meta
+    assert list(meta.keys()) == FLOW_META_KEYS
+    assert meta["frames"] == n and meta["flow_backend"] == "DIS" and meta["flow_fallback_reason"] is None
+    em = meta["estimated_motion"]
+    pdim = {"translation": 2, "similarity": 4}[mode]
+    assert len(em["per_transition"]) == n - 1 and [t["index"] for t in em["per_transition"]] == list(range(n - 1))
+    assert np.array(em["path"]).shape == (n, pdim) and np.array(em["target_path"]).shape == (n, pdim)
+    assert len(meta["stabilization_warp"]["per_frame"]) == n and meta["motion_meta"]["frame_count"] == n
+    assert meta["motion_meta"]["version"] == 2 and meta["motion_meta"]["source"] == "estimated_flow"
+    json.dumps(meta)  # plain JSON types only
+    # --- estimation stages vs oracle
+    work = api.hm._working_estimation_size(w, h)
+    g = oracle.gray_for_estimation(frames, work)
+    flow = oracle.dis_flow_clip(g)
+    recs = []
+    for i in range(n - 1):
+        r, nv, nt = oracle.fit_all_modes(flow[i], 8, mode)
+        recs.append(r)
+    mats, modes, confs, resids, active = api.fp.select_transitions(recs, mode)
+    assert meta["transform_mode_applied"] == active
+    for i, t in enumerate(em["per_transition"]):
+        assert t["mode"] == modes[i] and t["confidence"] == confs[i]
+        full = api.hm._rescale_transform_to_full(mats[i], (w, h), work) if work else mats[i]
+        assert np.allclose(np.array(t["matrix"], np.float32), full, rtol=0, atol=2e-5 if work else 1e-6)
+        assert t["residual"] == pytest.approx(resids[i], rel=1e-6)
+    # known motion is recovered (independent of the oracle)
+    def to_texture(pr):  # frame coords -> texture coords of moving_clip()
+        tx, ty, th, sc = pr
+        c, sn = np.cos(th) / sc, np.sin(th) / sc
+        lin = np.array([[c, sn, 0], [-sn, c, 0], [0, 0, 1.0]])
+        pre = np.array([[1, 0, -w / 2 - tx], [0, 1, -h / 2 - ty], [0, 0, 1.0]])
+        post = np.array([[1, 0, w / 2], [0, 1, h / 2], [0, 0, 1.0]])
+        return post @ lin @ pre
+
+    for i, t in enumerate(em["per_transition"]):
+        expect = np.linalg.inv(to_texture(params[i + 1])) @ to_texture(params[i])
+        got = np.array(t["matrix"])
+        assert np.abs(got[:2, :2] - expect[:2, :2]).max() < (2e-3 if mode == "similarity" else 2e-2)
+        assert np.abs(got[:2, 2] - expect[:2, 2]).max() < (0.6 if mode == "similarity" else 2.5)
+    # --- warp vs oracle with the node's own matrices
+    fm = np.array([e["applied_matrix"] for e in meta["stabilization_warp"]["per_frame"]], np.float32)
+    out_size = tuple(meta["stabilization_warp"]["output_size"])
+    ref, ref_mask, cnt = oracle.warp_clip(frames, fm, out_size, border=BORDER)
+    assert np.array_equal(res.frames, ref) and np.array_equal(res.masks[..., 0], ref_mask)
+    ratios = [float(np.float32(k) / np.float32(out_size[0] * out_size[1])) for k in cnt]
+    assert meta["padding_fraction_mean"] == float(np.mean(ratios)) and meta["padding_fraction_max"] == float(np.max(ratios))
+    assert meta["framing"]["padding_detected"] == bool(cnt.max() > 0)
+    if framing == "expand":
+        assert meta["framing"]["expanded_size"] == list(out_size) and res.frames.shape[1:3] == (out_size[1], out_size[0])
+    # --- KA7: Motion Apply replay of the stabilizer's own meta is bit-identical
+    replay = api.ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop_and_pad")
+    assert np.array_equal(replay.frames, res.frames) and np.array_equal(replay.masks, res.masks)
+
+
+def test_flow_node_small_paths(api, ctx):
+    """F15: single frame passthrough; camera_lock; crop bypass at keep_fov ~ 1; dict input keeps its template."""
+    import torch
+
+    frames = synth_frames(1, 60, 80)
+    out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    assert np.array_equal(out[0].numpy(), frames) and out[2]["note"].startswith("Single-frame") and out[2]["motion_meta"]["frame_count"] == 1
+    frames = synth_frames(5, 136, 240)
+    out = api.nodes.VideoStabilizerFlow.execute({"frames": torch.from_numpy(frames), "fps": 24.0, "tag": "x"}, 0.0, "crop", "similarity", True, 0.7,
+                                                0.5, 1.0, "#102030")
+    assert isinstance(out[0], dict) and out[0]["tag"] == "x" and np.array_equal(out[0]["frames"].numpy(), frames)
+    assert out[2]["fps_effective"] == 24.0 and out[2]["fps_requested"] is None and out[2]["transform_mode_applied"] == "identity"
+    out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop_and_pad", "similarity", True, 0.7, 0.2, 0.6, "#7F7F7F")
+    assert out[2]["smooth"] == 0.85 and np.all(np.array(out[2]["estimated_motion"]["target_path"]) == 0.0)
+    with pytest.raises(NotImplementedError):
+        api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
