@@ -78,6 +78,17 @@ int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** de
     return 0;
 }
 
+EventPair* vstab_timer_slot(vstab_ctx* ctx, const char* kind)
+{
+    auto it = ctx->timers.find(kind);
+    if (it == ctx->timers.end()) {
+        EventPair ep;
+        if (hipEventCreate(&ep.start) != hipSuccess || hipEventCreate(&ep.stop) != hipSuccess) return nullptr;
+        it = ctx->timers.emplace(kind, ep).first;
+    }
+    return &it->second;
+}
+
 extern "C" {
 
 int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
@@ -97,8 +108,6 @@ int vstab_create(vstab_ctx** out, int device)
     ctx->device = device;
     ctx->h_params.pinned_host = true;
     ctx->h_fit.pinned_host = true;
-    VSTAB_HIP(hipEventCreate(&ctx->ev_start));
-    VSTAB_HIP(hipEventCreate(&ctx->ev_stop));
     VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_params_free, hipEventDisableTiming));
     VSTAB_HIP(hipEventRecord(ctx->ev_params_free, nullptr));
     *out = ctx;
@@ -116,8 +125,7 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->d_fit.release();
     ctx->h_fit.release();
     ctx->d_gray_tmp.release();
-    (void)hipEventDestroy(ctx->ev_start);
-    (void)hipEventDestroy(ctx->ev_stop);
+    for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
     delete ctx;
     return 0;
@@ -147,9 +155,10 @@ int vstab_set_timing(vstab_ctx* ctx, int enabled)
 int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out)
 {
     VSTAB_REQUIRE(ctx != nullptr && kind != nullptr && ms_out != nullptr, "vstab_last_kernel_ms: NULL argument");
-    auto it = ctx->last_ms.find(kind);
-    VSTAB_REQUIRE(it != ctx->last_ms.end(), "vstab_last_kernel_ms: no timing recorded for '%s'", kind);
-    *ms_out = it->second;
+    auto it = ctx->timers.find(kind);
+    VSTAB_REQUIRE(it != ctx->timers.end() && it->second.pending, "vstab_last_kernel_ms: no timing recorded for '%s'", kind);
+    VSTAB_HIP(hipEventSynchronize(it->second.stop));
+    VSTAB_HIP(hipEventElapsedTime(ms_out, it->second.start, it->second.stop));
     return 0;
 }
 

@@ -38,12 +38,13 @@ struct ScratchBuf {
     void release();
 };
 
+struct EventPair { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; };
+
 struct vstab_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::map<std::string, float> last_ms;
+    std::map<std::string, EventPair> timers;
     // staging for small per-call parameter tables (pinned host + device mirror)
     ScratchBuf h_params, d_params;
     hipEvent_t ev_params_free = nullptr;  // recorded after the H2D copy of h_params
@@ -54,19 +55,23 @@ struct vstab_ctx {
 // Upload `bytes` of host data through the pinned staging buffer; returns device pointer.
 int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** dev_out);
 
+// Brackets the kernels of one API call with HIP events recorded on the call's stream (no host
+// sync here: vstab_last_kernel_ms waits for the stop event when the number is asked for).
+EventPair* vstab_timer_slot(vstab_ctx* ctx, const char* kind);
+
 struct KernelTimer {
     vstab_ctx* ctx;
-    const char* kind;
-    KernelTimer(vstab_ctx* c, const char* k) : ctx(c), kind(k) {
-        if (ctx->timing) (void)hipEventRecord(ctx->ev_start, ctx->stream);
+    EventPair* ev = nullptr;
+    KernelTimer(vstab_ctx* c, const char* k) : ctx(c) {
+        if (ctx->timing) {
+            ev = vstab_timer_slot(ctx, k);
+            if (ev) (void)hipEventRecord(ev->start, ctx->stream);
+        }
     }
     ~KernelTimer() {
-        if (ctx->timing) {
-            (void)hipEventRecord(ctx->ev_stop, ctx->stream);
-            (void)hipEventSynchronize(ctx->ev_stop);
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop);
-            ctx->last_ms[kind] = ms;
+        if (ev) {
+            (void)hipEventRecord(ev->stop, ctx->stream);
+            ev->pending = true;
         }
     }
 };

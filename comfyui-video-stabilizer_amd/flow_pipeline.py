@@ -14,6 +14,7 @@ The host keeps only what is sequential or scalar in the reference (flow.py:324-3
 
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -101,6 +102,183 @@ def _host_frames(context: hm.VideoContext) -> np.ndarray:
     return np.stack([hm._ensure_rgb(f) for f in context.frames], axis=0)
 
 
+@dataclass
+class FlowPlan:
+    """Everything the warp stage and the meta need, derived on the host from the per-pair fits
+    (replicated on every rank in multi-GPU runs: deterministic fp64 / integer logic only)."""
+
+    final_matrices: List[np.ndarray]
+    output_size: Tuple[int, int]
+    meta_head: Dict[str, Any]          # keys of flow.py:598-611 that do not depend on the warp
+    framing_meta: Dict[str, Any]
+    estimated_motion: Dict[str, Any]
+    framing_mode: str
+    source_size: Tuple[int, int]
+    fps_effective: float
+    bypass_meta: Optional[Dict[str, Any]] = None
+
+
+def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
+                       keep_fov, padding_rgb, fps_effective, fps_requested) -> FlowPlan:
+    """flow.py:324-546 for a whole clip: sticky-mode selection, parameter deltas, trajectory (HIP fp64),
+    framing geometry.  `fit_records` covers all N-1 transitions of the clip."""
+    width, height = size
+    rgb_list = [int(c) for c in padding_rgb]
+    flow_backend, flow_fallback_reason = "DIS", None
+    base_mode = transform_mode
+    working_size = hm._working_estimation_size(width, height)
+    work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
+    matrices = [hm._rescale_transform_to_full(m, size, working_size) if working_size is not None else m
+                for m in work_mats]
+    delta_params = np.stack([hm._matrix_to_params(m, base_mode) for m in matrices], axis=0)
+
+    # ---- trajectory (F7-F8) --------------------------------------------------
+    strength = float(np.clip(strength, 0.0, 1.0))
+    smooth = float(np.clip(smooth, 0.0, 1.0))
+    path, target_path = ctx.trajectory(delta_params, smooth, fps_effective, strength, bool(camera_lock))
+    if camera_lock:
+        smooth = max(smooth, 0.85)
+    diffs = target_path - path
+
+    keep_fov_clamped = float(np.clip(keep_fov, 0.0, 1.0))
+    keep_fov_applied = framing_mode == "crop" and keep_fov_clamped > 1e-6
+    stabilization_scale = 1.0
+
+    if framing_mode == "crop":
+        if keep_fov_clamped >= 0.9999:  # flow.py:387-429: return the original frames
+            meta = {
+                "frames": total_frames,
+                "note": "keep_fov~=1.0 in crop mode; returning original frames.",
+                "transform_mode_requested": transform_mode,
+                "transform_mode_applied": "identity",
+                "camera_lock": camera_lock,
+                "strength": strength,
+                "strength_effective": 0.0,
+                "smooth": smooth,
+                "fps_requested": fps_requested,
+                "fps_effective": fps_effective,
+                "framing": {
+                    "mode": framing_mode,
+                    "input_size": list(size),
+                    "keep_fov_requested": keep_fov_clamped,
+                    "keep_fov_effective": 1.0,
+                    "min_content_ratio": 1.0,
+                    "padding_color_rgb": rgb_list,
+                    "stabilization_scale": 0.0,
+                },
+                "keep_fov_applied": False,
+                "flow_backend": flow_backend,
+                "flow_fallback_reason": flow_fallback_reason,
+                "stabilization_warp": hm._build_stabilization_warp_meta(
+                    source_size=size, output_size=size, framing_mode=framing_mode,
+                    applied_matrices=[np.eye(3, dtype=np.float32) for _ in range(total_frames)]),
+                "estimated_motion": {
+                    "per_transition": [],
+                    "path": path.tolist(),
+                    "target_path": target_path.tolist(),
+                    "target_path_effective": path.tolist(),
+                },
+                "padding_fraction_mean": 0.0,
+                "padding_fraction_max": 0.0,
+            }
+            return FlowPlan([], size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta)
+        raise NotImplementedError(
+            "framing_mode='crop' (keep_fov crop solver, stabilizer_utils.py:448-837) is outside the hot path "
+            "built so far; use 'crop_and_pad' or 'expand'.")
+
+    apply_matrices = [hm._params_to_matrix(d, base_mode) for d in diffs]
+    output_size = size
+    mins, maxs = hm._compute_bounding_boxes(apply_matrices, width, height)
+    framing_meta: Dict[str, Any] = {
+        "mode": framing_mode,
+        "input_size": list(size),
+        "padding_color_rgb": rgb_list,
+        "min_content_ratio": hm._min_content_ratio(mins, maxs, width, height),
+    }
+    if framing_mode == "crop_and_pad":  # flow.py:500-529
+        x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1]))
+        x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
+        inter_w, inter_h = max(1.0, x1 - x0), max(1.0, y1 - y0)
+        off_x = width * 0.5 - (x0 + x1) * 0.5
+        off_y = height * 0.5 - (y0 + y1) * 0.5
+        shift = np.array([[1.0, 0.0, off_x], [0.0, 1.0, off_y], [0.0, 0.0, 1.0]], dtype=np.float32)
+        final_matrices = [shift @ m for m in apply_matrices]
+        framing_meta.update({
+            "safe_region_origin": [x0, y0],
+            "safe_region_size": [inter_w, inter_h],
+            "actual_content_ratio": min(inter_w / width, inter_h / height),
+            "center_offset": [off_x, off_y],
+        })
+    elif framing_mode == "expand":  # flow.py:530-533
+        shift, output_size = hm._prepare_expand_transform(mins, maxs)
+        final_matrices = [shift @ m for m in apply_matrices]
+        framing_meta["expanded_size"] = list(output_size)
+    else:
+        raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
+
+    stabilization_scale = float(np.clip(stabilization_scale, 0.0, 1.0))
+    effective_target_path = path + diffs
+    meta_head = {
+        "frames": total_frames,
+        "transform_mode_requested": transform_mode,
+        "transform_mode_applied": active_mode,
+        "camera_lock": camera_lock,
+        "strength": strength,
+        "strength_effective": strength * stabilization_scale,
+        "smooth": smooth,
+        "fps_requested": fps_requested,
+        "fps_effective": fps_effective,
+        "keep_fov_applied": keep_fov_applied,
+        "padding_color_rgb": rgb_list,
+        "flow_backend": flow_backend,
+        "flow_fallback_reason": flow_fallback_reason,
+    }
+    estimated_motion = {
+        "per_transition": [
+            {"index": i, "mode": mode, "confidence": conf, "residual": resid,
+             "matrix": matrices[i].astype(np.float32).tolist()}
+            for i, (mode, conf, resid) in enumerate(zip(modes_used, confidences, residuals))
+        ],
+        "path": path.tolist(),
+        "target_path": target_path.tolist(),
+        "target_path_effective": effective_target_path.tolist(),
+    }
+    return FlowPlan(final_matrices, output_size, meta_head, framing_meta, estimated_motion, framing_mode, size, fps_effective)
+
+
+def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
+    """flow.py:583-640: padding statistics from the per-frame padded-pixel counts + the final dict."""
+    counts = np.asarray(pad_counts, dtype=np.int64)
+    pixels = np.float32(plan.output_size[0] * plan.output_size[1])
+    padded_ratios = [float(np.float32(c) / pixels) for c in counts]  # mask.mean() in float32 (flow.py:587)
+    framing_meta = dict(plan.framing_meta)
+    framing_meta["padding_detected"] = bool((counts > 0).any())
+    h = plan.meta_head
+    meta = {
+        "frames": h["frames"],
+        "transform_mode_requested": h["transform_mode_requested"],
+        "transform_mode_applied": h["transform_mode_applied"],
+        "camera_lock": h["camera_lock"],
+        "strength": h["strength"],
+        "strength_effective": h["strength_effective"],
+        "smooth": h["smooth"],
+        "fps_requested": h["fps_requested"],
+        "fps_effective": h["fps_effective"],
+        "framing": framing_meta,
+        "keep_fov_applied": h["keep_fov_applied"],
+        "padding_color_rgb": h["padding_color_rgb"],
+        "flow_backend": h["flow_backend"],
+        "flow_fallback_reason": h["flow_fallback_reason"],
+        "stabilization_warp": hm._build_stabilization_warp_meta(
+            source_size=plan.source_size, output_size=plan.output_size, framing_mode=plan.framing_mode,
+            applied_matrices=plan.final_matrices),
+        "estimated_motion": plan.estimated_motion,
+        "padding_fraction_mean": float(np.mean(padded_ratios)),
+        "padding_fraction_max": float(np.max(padded_ratios)),
+    }
+    return _attach_motion_meta(meta, plan.fps_effective)
+
+
 def _stabilize_frames(
     context: hm.VideoContext,
     framing_mode: str,
@@ -114,10 +292,9 @@ def _stabilize_frames(
     *,
     ctx: Optional[native.Context] = None,
     keep_on_device: bool = False,
-    transition_provider=None,
 ) -> hm.StabilizationResult:
     """Positional signature of the reference (flow.py:213-223); keyword-only extras select the GPU
-    context, keep outputs resident in HBM, or inject another estimator (multi-GPU sharding)."""
+    context or keep outputs resident in HBM (multi-GPU sharding lives in distributed.py)."""
     total_frames = len(context.frames)
     fps_effective, fps_requested = _fps_fields(context, frame_rate)
     size = (context.width, context.height)
@@ -175,154 +352,29 @@ def _stabilize_frames(
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
     working_size = hm._working_estimation_size(context.width, context.height)
-    base_mode = transform_mode
 
     # ---- estimation (F2-F5) -------------------------------------------------
-    if transition_provider is not None:
-        fit_records = transition_provider(ctx, device_frames, working_size, transform_mode)
-    else:
-        fit_records = estimate_transitions(ctx, device_frames, working_size, transform_mode)
-    work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
-    matrices = [hm._rescale_transform_to_full(m, size, working_size) if working_size is not None else m
-                for m in work_mats]
-    delta_params = np.stack([hm._matrix_to_params(m, base_mode) for m in matrices], axis=0)
+    fit_records = estimate_transitions(ctx, device_frames, working_size, transform_mode)
     progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
     check_interrupt()
 
-    # ---- trajectory (F7-F8) --------------------------------------------------
-    strength = float(np.clip(strength, 0.0, 1.0))
-    smooth = float(np.clip(smooth, 0.0, 1.0))
-    path, target_path = ctx.trajectory(delta_params, smooth, fps_effective, strength, bool(camera_lock))
-    if camera_lock:
-        smooth = max(smooth, 0.85)
-    diffs = target_path - path
-
-    keep_fov_clamped = float(np.clip(keep_fov, 0.0, 1.0))
-    keep_fov_applied = framing_mode == "crop" and keep_fov_clamped > 1e-6
-    stabilization_scale = 1.0
-
-    if framing_mode == "crop":
-        if keep_fov_clamped >= 0.9999:  # flow.py:387-429: return the original frames
-            meta = {
-                "frames": total_frames,
-                "note": "keep_fov~=1.0 in crop mode; returning original frames.",
-                "transform_mode_requested": transform_mode,
-                "transform_mode_applied": "identity",
-                "camera_lock": camera_lock,
-                "strength": strength,
-                "strength_effective": 0.0,
-                "smooth": smooth,
-                "fps_requested": fps_requested,
-                "fps_effective": fps_effective,
-                "framing": {
-                    "mode": framing_mode,
-                    "input_size": list(size),
-                    "keep_fov_requested": keep_fov_clamped,
-                    "keep_fov_effective": 1.0,
-                    "min_content_ratio": 1.0,
-                    "padding_color_rgb": rgb_list,
-                    "stabilization_scale": 0.0,
-                },
-                "keep_fov_applied": False,
-                "flow_backend": flow_backend,
-                "flow_fallback_reason": flow_fallback_reason,
-                "stabilization_warp": hm._build_stabilization_warp_meta(
-                    source_size=size, output_size=size, framing_mode=framing_mode,
-                    applied_matrices=[np.eye(3, dtype=np.float32) for _ in range(total_frames)]),
-                "estimated_motion": {
-                    "per_transition": [],
-                    "path": path.tolist(),
-                    "target_path": target_path.tolist(),
-                    "target_path_effective": path.tolist(),
-                },
-                "padding_fraction_mean": 0.0,
-                "padding_fraction_max": 0.0,
-            }
-            pbar.update_absolute(progress_total, progress_total)
-            frames_out = device_frames if keep_on_device else _host_frames(context)
-            masks_out = (ctx.torch.zeros((total_frames, context.height, context.width, 1), device=ctx.device)
-                         if keep_on_device else np.zeros((total_frames, context.height, context.width, 1), np.float32))
-            return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(meta, fps_effective))
-        raise NotImplementedError(
-            "framing_mode='crop' (keep_fov crop solver, stabilizer_utils.py:448-837) is outside the hot path "
-            "built so far; use 'crop_and_pad' or 'expand'.")
-
-    apply_matrices = [hm._params_to_matrix(d, base_mode) for d in diffs]
-    output_size = size
-    mins, maxs = hm._compute_bounding_boxes(apply_matrices, context.width, context.height)
-    framing_meta: Dict[str, Any] = {
-        "mode": framing_mode,
-        "input_size": list(size),
-        "padding_color_rgb": rgb_list,
-        "min_content_ratio": hm._min_content_ratio(mins, maxs, context.width, context.height),
-    }
-    if framing_mode == "crop_and_pad":  # flow.py:500-529
-        x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1]))
-        x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
-        inter_w, inter_h = max(1.0, x1 - x0), max(1.0, y1 - y0)
-        off_x = context.width * 0.5 - (x0 + x1) * 0.5
-        off_y = context.height * 0.5 - (y0 + y1) * 0.5
-        shift = np.array([[1.0, 0.0, off_x], [0.0, 1.0, off_y], [0.0, 0.0, 1.0]], dtype=np.float32)
-        final_matrices = [shift @ m for m in apply_matrices]
-        framing_meta.update({
-            "safe_region_origin": [x0, y0],
-            "safe_region_size": [inter_w, inter_h],
-            "actual_content_ratio": min(inter_w / context.width, inter_h / context.height),
-            "center_offset": [off_x, off_y],
-        })
-    elif framing_mode == "expand":  # flow.py:530-533
-        shift, output_size = hm._prepare_expand_transform(mins, maxs)
-        final_matrices = [shift @ m for m in apply_matrices]
-        framing_meta["expanded_size"] = list(output_size)
-    else:
-        raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
-
-    stabilization_scale = float(np.clip(stabilization_scale, 0.0, 1.0))
-    effective_target_path = path + diffs
+    plan = plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength,
+                              smooth, keep_fov, padding_rgb, fps_effective, fps_requested)
+    if plan.bypass_meta is not None:  # crop + keep_fov ~ 1 (flow.py:387-429): original frames
+        pbar.update_absolute(progress_total, progress_total)
+        frames_out = device_frames if keep_on_device else _host_frames(context)
+        masks_out = (ctx.torch.zeros((total_frames, context.height, context.width, 1), device=ctx.device)
+                     if keep_on_device else np.zeros((total_frames, context.height, context.width, 1), np.float32))
+        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(plan.bypass_meta, fps_effective))
 
     # ---- warp (F13) ------------------------------------------------------------
     dst, mask, counts = ctx.warp_batch(
-        device_frames, np.stack(final_matrices).astype(np.float32), output_size, interp="bilinear",
+        device_frames, np.stack(plan.final_matrices).astype(np.float32), plan.output_size, interp="bilinear",
         border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
     counts_host = counts.cpu().numpy().astype(np.int64)
-    pixels = np.float32(output_size[0] * output_size[1])
-    padded_ratios = [float(np.float32(c) / pixels) for c in counts_host]  # mask.mean() in float32 (flow.py:587)
-    padding_detected = bool((counts_host > 0).any())
-    framing_meta["padding_detected"] = padding_detected
     progress_done = _replay_progress(pbar, progress_done, total_frames, progress_total)
     check_interrupt()
-
-    meta = {
-        "frames": total_frames,
-        "transform_mode_requested": transform_mode,
-        "transform_mode_applied": active_mode,
-        "camera_lock": camera_lock,
-        "strength": strength,
-        "strength_effective": strength * stabilization_scale,
-        "smooth": smooth,
-        "fps_requested": fps_requested,
-        "fps_effective": fps_effective,
-        "framing": framing_meta,
-        "keep_fov_applied": keep_fov_applied,
-        "padding_color_rgb": rgb_list,
-        "flow_backend": flow_backend,
-        "flow_fallback_reason": flow_fallback_reason,
-        "stabilization_warp": hm._build_stabilization_warp_meta(
-            source_size=size, output_size=output_size, framing_mode=framing_mode, applied_matrices=final_matrices),
-        "estimated_motion": {
-            "per_transition": [
-                {"index": i, "mode": mode, "confidence": conf, "residual": resid,
-                 "matrix": matrices[i].astype(np.float32).tolist()}
-                for i, (mode, conf, resid) in enumerate(zip(modes_used, confidences, residuals))
-            ],
-            "path": path.tolist(),
-            "target_path": target_path.tolist(),
-            "target_path_effective": effective_target_path.tolist(),
-        },
-        "padding_fraction_mean": float(np.mean(padded_ratios)),
-        "padding_fraction_max": float(np.max(padded_ratios)),
-    }
-    meta = _attach_motion_meta(meta, fps_effective)
+    meta = finish_meta(plan, counts_host)
     if keep_on_device:
         return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
     return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)
