@@ -377,226 +377,165 @@ __global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
     for (int k = lane; k < cnt; k += 64) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
 }
 
-__global__ __launch_bounds__(256) void densify_kernel(const uint8_t* __restrict__ I, const float* __restrict__ Sx, const float* __restrict__ Sy,
-                                                      float* __restrict__ U, float* __restrict__ V, int P, int h, int w, int ws, int hs)
-{
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(t, total) {
-        const int j = (int)(t % w);
-        const long long rr = t / w;
-        const int i = (int)(rr % h);
-        const int p = (int)(rr / h);
-        const uint8_t* I0 = I + (size_t)p * h * w;
-        const uint8_t* I1 = I + (size_t)(p + 1) * h * w;
-        const float* sx = Sx + (size_t)p * hs * ws;
-        const float* sy = Sy + (size_t)p * hs * ws;
-        int end_is = i / PSTR < hs - 1 ? i / PSTR : hs - 1;
-        int start_is = i - PSZ >= 0 ? (i - PSZ) / PSTR + 1 : 0;
-        if (start_is > end_is) start_is = end_is;
-        int end_js = j / PSTR < ws - 1 ? j / PSTR : ws - 1;
-        int start_js = j - PSZ >= 0 ? (j - PSZ) / PSTR + 1 : 0;
-        if (start_js > end_js) start_js = end_js;
-        const float i0 = (float)I0[(size_t)i * w + j];
-        float sum_coef = 0.f, sum_Ux = 0.f, sum_Uy = 0.f;
-        for (int is = start_is; is <= end_is; is++)
-            for (int js = start_js; js <= end_js; js++) {
-                const float sxv = sx[(size_t)is * ws + js], syv = sy[(size_t)is * ws + js];
-                float j_m = (float)j + sxv, i_m = (float)i + syv;
-                j_m = j_m > 0.0f ? j_m : 0.0f;
-                j_m = j_m < (float)w - 1.0f - DIS_EPS ? j_m : (float)w - 1.0f - DIS_EPS;
-                i_m = i_m > 0.0f ? i_m : 0.0f;
-                i_m = i_m < (float)h - 1.0f - DIS_EPS ? i_m : (float)h - 1.0f - DIS_EPS;
-                const int j_l = (int)j_m, j_u = j_l + 1, i_l = (int)i_m, i_u = i_l + 1;
-                const float diff = (j_m - j_l) * (i_m - i_l) * I1[(size_t)i_u * w + j_u] +
-                                   (j_u - j_m) * (i_m - i_l) * I1[(size_t)i_u * w + j_l] +
-                                   (j_m - j_l) * (i_u - i_m) * I1[(size_t)i_l * w + j_u] +
-                                   (j_u - j_m) * (i_u - i_m) * I1[(size_t)i_l * w + j_l] - i0;
-                const float ad = __builtin_fabsf(diff);
-                const float coef = 1 / (ad > 1.0f ? ad : 1.0f);
-                sum_Ux += coef * sxv;
-                sum_Uy += coef * syv;
-                sum_coef += coef;
-            }
-        U[t] = sum_Ux / sum_coef;
-        V[t] = sum_Uy / sum_coef;
-    }
-}
-
-// ---- variational refinement ---------------------------------------------------------------
+// ---- per-pixel phase bodies (shared by every launch shape) -----------------------------------
+// All indices below are GLOBAL element indices into the [P][h][w] planes; (x, y) is the pixel.
 struct VrBufs {
     float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *A11, *A12, *A22, *b1, *b2, *wgt, *tU, *tV, *dU, *dV;
 };
 
-__global__ __launch_bounds__(256) void vr_warp_kernel(const uint8_t* __restrict__ I, const float* __restrict__ U, const float* __restrict__ V,
-                                                      VrBufs b, int P, int h, int w)
+__device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ sx,
+                                           const float* __restrict__ sy, float* __restrict__ U, float* __restrict__ V, long long t, int i,
+                                           int j, int h, int w, int ws, int hs)
 {
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % w);
-        const long long rr = t / w;
-        const int y = (int)(rr % h);
-        const int p = (int)(rr / h);
-        const uint8_t* I0 = I + (size_t)p * h * w;
-        const uint8_t* I1 = I + (size_t)(p + 1) * h * w;
-        const float u = U[t], v = V[t];
-        const float mx = x + u, my = y + v;
-        const int sx = (int)__builtin_rintf(mx * 32.f), sy = (int)__builtin_rintf(my * 32.f);
-        const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
-        const int fx = sx & 31, fy = sy & 31;
-        const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1, wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
-        const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
-        const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
-        const float v00 = (float)I1[(size_t)y0 * w + x0], v01 = (float)I1[(size_t)y0 * w + x1];
-        const float v10 = (float)I1[(size_t)y1 * w + x0], v11 = (float)I1[(size_t)y1 * w + x1];
-        const float warped = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
-        const float i0 = (float)I0[(size_t)y * w + x];
-        b.avg[t] = i0 * 0.5f + warped * 0.5f + 0.f;
-        b.Iz[t] = warped - i0;
-        b.tU[t] = u;
-        b.tV[t] = v;
-        b.dU[t] = 0.f;
-        b.dV[t] = 0.f;
-    }
-}
-
-__global__ __launch_bounds__(256) void vr_deriv1_kernel(VrBufs b, int P, int h, int w)
-{
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % w);
-        const int y = (int)((t / w) % h);
-        const long long base = t - (long long)y * w - x;
-        const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
-        const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
-        b.Ix[t] = b.avg[xr] - b.avg[xl];
-        b.Iy[t] = b.avg[yd] - b.avg[yu];
-        b.Ixz[t] = b.Iz[xr] - b.Iz[xl];
-        b.Iyz[t] = b.Iz[yd] - b.Iz[yu];
-    }
-}
-
-__global__ __launch_bounds__(256) void vr_deriv2_kernel(VrBufs b, int P, int h, int w)
-{
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % w);
-        const int y = (int)((t / w) % h);
-        const long long base = t - (long long)y * w - x;
-        const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
-        const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
-        b.Ixx[t] = b.Ix[xr] - b.Ix[xl];
-        b.Ixy[t] = b.Ix[yd] - b.Ix[yu];
-        b.Iyy[t] = b.Iy[yd] - b.Iy[yu];
-    }
-}
-
-__global__ __launch_bounds__(256) void vr_weights_kernel(VrBufs b, int P, int h, int w, float alpha2, float eps2)
-{
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % w);
-        const int y = (int)((t / w) % h);
-        const long long qr = (x + 1 < w) ? t + 1 : t;
-        const long long qd = (y + 1 < h) ? t + w : t;
-        const float ux = b.tU[qr] - b.tU[t], vx = b.tV[qr] - b.tV[t];
-        const float uy = b.tU[qd] - b.tU[t], vy = b.tV[qd] - b.tV[t];
-        b.wgt[t] = alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
-    }
-}
-
-__global__ __launch_bounds__(256) void vr_system_kernel(VrBufs b, const float* __restrict__ U, const float* __restrict__ V, int P, int h, int w,
-                                                        float delta2, float gamma2, float zeta2, float eps2)
-{
-    const long long total = (long long)P * h * w;
-    GRID_STRIDE(q, total) {
-        const int x = (int)(q % w);
-        const int y = (int)((q / w) % h);
-        const float Ix = b.Ix[q], Iy = b.Iy[q], Iz = b.Iz[q], Ixx = b.Ixx[q], Ixy = b.Ixy[q], Iyy = b.Iyy[q], Ixz = b.Ixz[q], Iyz = b.Iyz[q];
-        const float du = b.dU[q], dv = b.dV[q];
-        float a11, a12, a22, B1, B2;
-        {
-            float derivNorm = Ix * Ix + Iy * Iy + zeta2;
-            float Ik1z = Iz + Ix * du + Iy * dv;
-            float weight = delta2 / __builtin_sqrtf(Ik1z * Ik1z / derivNorm + eps2);
-            a11 = weight * (Ix * Ix / derivNorm) + zeta2;
-            a12 = weight * (Ix * Iy / derivNorm);
-            a22 = weight * (Iy * Iy / derivNorm) + zeta2;
-            B1 = -weight * (Iz * Ix / derivNorm);
-            B2 = -weight * (Iz * Iy / derivNorm);
-            derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
-            float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
-            float Ik1zx = Ixz + Ixx * du + Ixy * dv;
-            float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-            weight = gamma2 / __builtin_sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
-            a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-            a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-            a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-            B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-            B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+    int end_is = i / PSTR < hs - 1 ? i / PSTR : hs - 1;
+    int start_is = i - PSZ >= 0 ? (i - PSZ) / PSTR + 1 : 0;
+    if (start_is > end_is) start_is = end_is;
+    int end_js = j / PSTR < ws - 1 ? j / PSTR : ws - 1;
+    int start_js = j - PSZ >= 0 ? (j - PSZ) / PSTR + 1 : 0;
+    if (start_js > end_js) start_js = end_js;
+    const float i0 = (float)I0[(size_t)i * w + j];
+    float sum_coef = 0.f, sum_Ux = 0.f, sum_Uy = 0.f;
+    for (int is = start_is; is <= end_is; is++)
+        for (int js = start_js; js <= end_js; js++) {
+            const float sxv = sx[(size_t)is * ws + js], syv = sy[(size_t)is * ws + js];
+            float j_m = (float)j + sxv, i_m = (float)i + syv;
+            j_m = j_m > 0.0f ? j_m : 0.0f;
+            j_m = j_m < (float)w - 1.0f - DIS_EPS ? j_m : (float)w - 1.0f - DIS_EPS;
+            i_m = i_m > 0.0f ? i_m : 0.0f;
+            i_m = i_m < (float)h - 1.0f - DIS_EPS ? i_m : (float)h - 1.0f - DIS_EPS;
+            const int j_l = (int)j_m, j_u = j_l + 1, i_l = (int)i_m, i_u = i_l + 1;
+            const float diff = (j_m - j_l) * (i_m - i_l) * I1[(size_t)i_u * w + j_u] +
+                               (j_u - j_m) * (i_m - i_l) * I1[(size_t)i_u * w + j_l] +
+                               (j_m - j_l) * (i_u - i_m) * I1[(size_t)i_l * w + j_u] +
+                               (j_u - j_m) * (i_u - i_m) * I1[(size_t)i_l * w + j_l] - i0;
+            const float ad = __builtin_fabsf(diff);
+            const float coef = 1 / (ad > 1.0f ? ad : 1.0f);
+            sum_Ux += coef * sxv;
+            sum_Uy += coef * syv;
+            sum_coef += coef;
         }
-        const bool red = ((x + y) & 1) == 0;
-        const bool has_r = x + 1 < w, has_l = x > 0, has_d = y + 1 < h, has_u = y > 0;
-        const float wq = b.wgt[q], uq = U[q], vq = V[q];
-        float own_hu = 0, own_hv = 0, left_hu = 0, left_hv = 0, wl = 0;
-        if (has_r) { own_hu = wq * (U[q + 1] - uq); own_hv = wq * (V[q + 1] - vq); }
-        if (has_l) { wl = b.wgt[q - 1]; left_hu = wl * (uq - U[q - 1]); left_hv = wl * (vq - V[q - 1]); }
-        float own_vu = 0, own_vv = 0, up_vu = 0, up_vv = 0, wu = 0;
-        if (has_d) { own_vu = wq * (U[q + w] - uq); own_vv = wq * (V[q + w] - vq); }
-        if (has_u) { wu = b.wgt[q - w]; up_vu = wu * (uq - U[q - w]); up_vv = wu * (vq - V[q - w]); }
-        if (red) {
-            if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-            if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-            if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-            if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-        } else {
-            if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-            if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-            if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-            if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-        }
-        b.A11[q] = a11; b.A12[q] = a12; b.A22[q] = a22; b.b1[q] = B1; b.b2[q] = B2;
-    }
+    U[t] = sum_Ux / sum_coef;
+    V[t] = sum_Uy / sum_coef;
 }
 
-// one colour of one red-black SOR sweep; thread = one pixel of that colour
-__global__ __launch_bounds__(256) void vr_sor_kernel(VrBufs b, int P, int h, int w, int color, float omega)
+__device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ U,
+                                           const float* __restrict__ V, const VrBufs& b, long long t, int x, int y, int h, int w)
 {
-    const int half_w = (w + 1) >> 1;
-    const long long total = (long long)P * h * half_w;
-    GRID_STRIDE(t, total) {
-        const int k = (int)(t % half_w);
-        const long long rr = t / half_w;
-        const int y = (int)(rr % h);
-        const long long p = rr / h;
-        const int x = 2 * k + ((y + color) & 1);
-        if (x >= w) continue;
-        const long long q = (p * h + y) * w + x;
-        const float wq = b.wgt[q];
-        const float wl = x > 0 ? b.wgt[q - 1] : 0.f, wu = y > 0 ? b.wgt[q - w] : 0.f;
-        const float dul = x > 0 ? b.dU[q - 1] : 0.f, dvl = x > 0 ? b.dV[q - 1] : 0.f;
-        const float dur = x + 1 < w ? b.dU[q + 1] : 0.f, dvr = x + 1 < w ? b.dV[q + 1] : 0.f;
-        const float duu = y > 0 ? b.dU[q - w] : 0.f, dvu = y > 0 ? b.dV[q - w] : 0.f;
-        const float dud = y + 1 < h ? b.dU[q + w] : 0.f, dvd = y + 1 < h ? b.dV[q + w] : 0.f;
-        const float sigmaU = wl * dul + wq * dur + wu * duu + wq * dud;
-        const float sigmaV = wl * dvl + wq * dvr + wu * dvu + wq * dvd;
-        const float a12 = b.A12[q];
-        float du = b.dU[q], dv = b.dV[q];
-        du += omega * ((sigmaU + b.b1[q] - dv * a12) / b.A11[q] - du);
-        dv += omega * ((sigmaV + b.b2[q] - du * a12) / b.A22[q] - dv);
-        b.dU[q] = du;
-        b.dV[q] = dv;
-    }
+    const float u = U[t], v = V[t];
+    const float mx = x + u, my = y + v;
+    const int sx = (int)__builtin_rintf(mx * 32.f), sy = (int)__builtin_rintf(my * 32.f);
+    const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+    const int fx = sx & 31, fy = sy & 31;
+    const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1, wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
+    const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+    const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+    const float v00 = (float)I1[(size_t)y0 * w + x0], v01 = (float)I1[(size_t)y0 * w + x1];
+    const float v10 = (float)I1[(size_t)y1 * w + x0], v11 = (float)I1[(size_t)y1 * w + x1];
+    const float warped = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
+    const float i0 = (float)I0[(size_t)y * w + x];
+    b.avg[t] = i0 * 0.5f + warped * 0.5f + 0.f;
+    b.Iz[t] = warped - i0;
+    b.tU[t] = u;
+    b.tV[t] = v;
+    b.dU[t] = 0.f;
+    b.dV[t] = 0.f;
 }
 
-// tempW = W + dW; on the last fixed-point iteration the result is also the level's output flow
-__global__ __launch_bounds__(256) void vr_update_kernel(VrBufs b, float* __restrict__ U, float* __restrict__ V, long long total, int last)
+__device__ __forceinline__ void vr_deriv1_px(const VrBufs& b, long long t, int x, int y, int h, int w)
 {
-    GRID_STRIDE(t, total) {
-        const float u = U[t] + b.dU[t], v = V[t] + b.dV[t];
-        b.tU[t] = u;
-        b.tV[t] = v;
-        if (last) { U[t] = u; V[t] = v; }
+    const long long base = t - (long long)y * w - x;
+    const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
+    const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
+    b.Ix[t] = b.avg[xr] - b.avg[xl];
+    b.Iy[t] = b.avg[yd] - b.avg[yu];
+    b.Ixz[t] = b.Iz[xr] - b.Iz[xl];
+    b.Iyz[t] = b.Iz[yd] - b.Iz[yu];
+}
+
+__device__ __forceinline__ void vr_deriv2_px(const VrBufs& b, long long t, int x, int y, int h, int w)
+{
+    const long long base = t - (long long)y * w - x;
+    const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
+    const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
+    b.Ixx[t] = b.Ix[xr] - b.Ix[xl];
+    b.Ixy[t] = b.Ix[yd] - b.Ix[yu];
+    b.Iyy[t] = b.Iy[yd] - b.Iy[yu];
+}
+
+__device__ __forceinline__ void vr_weights_px(const VrBufs& b, long long t, int x, int y, int h, int w, float alpha2, float eps2)
+{
+    const long long qr = (x + 1 < w) ? t + 1 : t;
+    const long long qd = (y + 1 < h) ? t + w : t;
+    const float ux = b.tU[qr] - b.tU[t], vx = b.tV[qr] - b.tV[t];
+    const float uy = b.tU[qd] - b.tU[t], vy = b.tV[qd] - b.tV[t];
+    b.wgt[t] = alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+}
+
+__device__ __forceinline__ void vr_system_px(const VrBufs& b, const float* __restrict__ U, const float* __restrict__ V, long long q, int x,
+                                             int y, int h, int w, float delta2, float gamma2, float zeta2, float eps2)
+{
+    const float Ix = b.Ix[q], Iy = b.Iy[q], Iz = b.Iz[q], Ixx = b.Ixx[q], Ixy = b.Ixy[q], Iyy = b.Iyy[q], Ixz = b.Ixz[q], Iyz = b.Iyz[q];
+    const float du = b.dU[q], dv = b.dV[q];
+    float a11, a12, a22, B1, B2;
+    {
+        float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+        float Ik1z = Iz + Ix * du + Iy * dv;
+        float weight = delta2 / __builtin_sqrtf(Ik1z * Ik1z / derivNorm + eps2);
+        a11 = weight * (Ix * Ix / derivNorm) + zeta2;
+        a12 = weight * (Ix * Iy / derivNorm);
+        a22 = weight * (Iy * Iy / derivNorm) + zeta2;
+        B1 = -weight * (Iz * Ix / derivNorm);
+        B2 = -weight * (Iz * Iy / derivNorm);
+        derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+        float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+        float Ik1zx = Ixz + Ixx * du + Ixy * dv;
+        float Ik1zy = Iyz + Ixy * du + Iyy * dv;
+        weight = gamma2 / __builtin_sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
+        a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+        a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+        a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+        B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+        B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
     }
+    const bool red = ((x + y) & 1) == 0;
+    const bool has_r = x + 1 < w, has_l = x > 0, has_d = y + 1 < h, has_u = y > 0;
+    const float wq = b.wgt[q], uq = U[q], vq = V[q];
+    float own_hu = 0, own_hv = 0, left_hu = 0, left_hv = 0, wl = 0;
+    if (has_r) { own_hu = wq * (U[q + 1] - uq); own_hv = wq * (V[q + 1] - vq); }
+    if (has_l) { wl = b.wgt[q - 1]; left_hu = wl * (uq - U[q - 1]); left_hv = wl * (vq - V[q - 1]); }
+    float own_vu = 0, own_vv = 0, up_vu = 0, up_vv = 0, wu = 0;
+    if (has_d) { own_vu = wq * (U[q + w] - uq); own_vv = wq * (V[q + w] - vq); }
+    if (has_u) { wu = b.wgt[q - w]; up_vu = wu * (uq - U[q - w]); up_vv = wu * (vq - V[q - w]); }
+    if (red) {
+        if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
+        if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
+        if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
+        if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
+    } else {
+        if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
+        if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
+        if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
+        if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
+    }
+    b.A11[q] = a11; b.A12[q] = a12; b.A22[q] = a22; b.b1[q] = B1; b.b2[q] = B2;
+}
+
+__device__ __forceinline__ void vr_sor_px(const VrBufs& b, long long q, int x, int y, int h, int w, float omega)
+{
+    const float wq = b.wgt[q];
+    const float wl = x > 0 ? b.wgt[q - 1] : 0.f, wu = y > 0 ? b.wgt[q - w] : 0.f;
+    const float dul = x > 0 ? b.dU[q - 1] : 0.f, dvl = x > 0 ? b.dV[q - 1] : 0.f;
+    const float dur = x + 1 < w ? b.dU[q + 1] : 0.f, dvr = x + 1 < w ? b.dV[q + 1] : 0.f;
+    const float duu = y > 0 ? b.dU[q - w] : 0.f, dvu = y > 0 ? b.dV[q - w] : 0.f;
+    const float dud = y + 1 < h ? b.dU[q + w] : 0.f, dvd = y + 1 < h ? b.dV[q + w] : 0.f;
+    const float sigmaU = wl * dul + wq * dur + wu * duu + wq * dud;
+    const float sigmaV = wl * dvl + wq * dvr + wu * dvu + wq * dvd;
+    const float a12 = b.A12[q];
+    float du = b.dU[q], dv = b.dV[q];
+    du += omega * ((sigmaU + b.b1[q] - dv * a12) / b.A11[q] - du);
+    dv += omega * ((sigmaV + b.b2[q] - du * a12) / b.A22[q] - dv);
+    b.dU[q] = du;
+    b.dV[q] = dv;
 }
 
 // ---- bilinear f32 resize (flow upsampling between levels), result scaled by `mul` ------------
@@ -609,33 +548,97 @@ __device__ __forceinline__ void lin_coord(int d, double scale, int ssize, int& s
     f = fx;
 }
 
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ sU, const float* __restrict__ sV, float* __restrict__ dU,
-                                                       float* __restrict__ dV, int P, int sh, int sw, int dh, int dw, double scale_x,
-                                                       double scale_y, float mul)
+__device__ __forceinline__ void upsample_px(const float* __restrict__ sU, const float* __restrict__ sV, float* __restrict__ dU,
+                                            float* __restrict__ dV, long long src_base, long long t, int dx, int dy, int sh, int sw,
+                                            double scale_x, double scale_y, float mul)
 {
-    const long long total = (long long)P * dh * dw;
-    GRID_STRIDE(t, total) {
-        const int dx = (int)(t % dw);
-        const long long rr = t / dw;
-        const int dy = (int)(rr % dh);
-        const long long p = rr / dh;
-        int sx, sy;
-        float fx, fy;
-        lin_coord(dx, scale_x, sw, sx, fx);
-        if (sx < 0) { fx = 0; sx = 0; }
-        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-        lin_coord(dy, scale_y, sh, sy, fy);
-        const int sy0 = clampi(sy, 0, sh - 1), sy1 = clampi(sy + 1, 0, sh - 1);
-        const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-        const float* S0 = sU + (p * sh + sy0) * sw;
-        const float* S1 = sU + (p * sh + sy1) * sw;
-        float r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
-        dU[t] = (r0 * b0 + r1 * b1) * mul;
-        S0 = sV + (p * sh + sy0) * sw;
-        S1 = sV + (p * sh + sy1) * sw;
-        r0 = S0[sx] * a0 + S0[sx1] * a1; r1 = S1[sx] * a0 + S1[sx1] * a1;
-        dV[t] = (r0 * b0 + r1 * b1) * mul;
+    int sx, sy;
+    float fx, fy;
+    lin_coord(dx, scale_x, sw, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    lin_coord(dy, scale_y, sh, sy, fy);
+    const int sy0 = clampi(sy, 0, sh - 1), sy1 = clampi(sy + 1, 0, sh - 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float* S0 = sU + src_base + (long long)sy0 * sw;
+    const float* S1 = sU + src_base + (long long)sy1 * sw;
+    float r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    dU[t] = (r0 * b0 + r1 * b1) * mul;
+    S0 = sV + src_base + (long long)sy0 * sw;
+    S1 = sV + src_base + (long long)sy1 * sw;
+    r0 = S0[sx] * a0 + S0[sx1] * a1; r1 = S1[sx] * a0 + S1[sx1] * a1;
+    dV[t] = (r0 * b0 + r1 * b1) * mul;
+}
+
+struct LevelArgs {
+    const uint8_t* I;   // [n][h][w] pyramid level
+    const float* Sx;    // [P][hs][ws]
+    const float* Sy;
+    float* U;           // [P][h][w]
+    float* V;
+    float* nextU;       // [P][nh][nw] (finer level) or nullptr
+    float* nextV;
+    VrBufs vb;
+    int P, h, w, ws, hs, nh, nw;
+    double up_sx, up_sy;
+    float alpha2, delta2, gamma2, zeta2, eps2, omega;
+};
+
+// One workgroup per frame pair runs densification, the whole variational refinement (5 fixed-point
+// iterations x 5 red-black SOR sweeps) and the x2 upsample to the next finer level.  The ~70 phases are
+// separated by workgroup barriers instead of kernel launches; the pair's planes stay in L2/Infinity Cache.
+__global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
+{
+    const int pair = blockIdx.x;
+    const int h = a.h, w = a.w;
+    const int npx = h * w;
+    const long long base = (long long)pair * npx;
+    const uint8_t* I0 = a.I + (size_t)pair * npx;
+    const uint8_t* I1 = a.I + (size_t)(pair + 1) * npx;
+    const float* sx = a.Sx + (size_t)pair * a.hs * a.ws;
+    const float* sy = a.Sy + (size_t)pair * a.hs * a.ws;
+    const VrBufs& b = a.vb;
+#define FOR_PX(...)                                                         \
+    for (int q_ = threadIdx.x; q_ < npx; q_ += blockDim.x) {                \
+        const int y = q_ / w, x = q_ - y * w;                               \
+        const long long t = base + q_;                                      \
+        __VA_ARGS__;                                                        \
+    }                                                                       \
+    __syncthreads();
+    FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
+    FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))
+    FOR_PX(vr_deriv1_px(b, t, x, y, h, w))
+    FOR_PX(vr_deriv2_px(b, t, x, y, h, w))
+    const int half_w = (w + 1) >> 1;
+    const int nhalf = h * half_w;
+    for (int it = 0; it < VAR_ITERS; it++) {
+        FOR_PX(vr_weights_px(b, t, x, y, h, w, a.alpha2, a.eps2))
+        FOR_PX(vr_system_px(b, a.U, a.V, t, x, y, h, w, a.delta2, a.gamma2, a.zeta2, a.eps2))
+        for (int s = 0; s < SOR_ITERS * 2; s++) {
+            const int color = s & 1;
+            for (int k_ = threadIdx.x; k_ < nhalf; k_ += blockDim.x) {
+                const int y = k_ / half_w;
+                const int x = 2 * (k_ - y * half_w) + ((y + color) & 1);
+                if (x < w) vr_sor_px(b, base + (long long)y * w + x, x, y, h, w, a.omega);
+            }
+            __syncthreads();
+        }
+        const bool last = it == VAR_ITERS - 1;
+        FOR_PX({
+            const float u = a.U[t] + b.dU[t], v = a.V[t] + b.dV[t];
+            b.tU[t] = u; b.tV[t] = v;
+            if (last) { a.U[t] = u; a.V[t] = v; }
+        })
+    }
+#undef FOR_PX
+    if (a.nextU != nullptr) {
+        const int nn = a.nh * a.nw;
+        const long long nbase = (long long)pair * nn;
+        for (int q_ = threadIdx.x; q_ < nn; q_ += blockDim.x) {
+            const int dy = q_ / a.nw, dx = q_ - dy * a.nw;
+            upsample_px(a.U, a.V, a.nextU, a.nextV, base, nbase + q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
+        }
     }
 }
 
@@ -796,7 +799,6 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
 
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
-        const long long px = (long long)P * g.h * g.w;
         PisArgs pa{};
         pa.I = I[i]; pa.Iext = Iext[i]; pa.Ix = Ixs[i]; pa.Iy = Iys[i]; pa.tensor = tensor[i];
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
@@ -805,31 +807,18 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
         const size_t lds_bytes = sizeof(float) * 2 * (size_t)pa.stripe_sz * g.ws;
         VSTAB_REQUIRE(lds_bytes <= 64 * 1024, "vstab_dis_flow_batch: stripe of %d x %d patches does not fit LDS", pa.stripe_sz, g.ws);
         hipLaunchKernelGGL(pis_kernel, dim3((unsigned)P * 8), dim3(64), lds_bytes, st, pa);
-        hipLaunchKernelGGL(densify_kernel, dim3(grid_for(px)), dim3(256), 0, st, I[i], Sx, Sy, Ul[i], Vl[i], P, g.h, g.w, g.ws, g.hs);
-        // variational refinement (calcUV)
-        hipLaunchKernelGGL(vr_warp_kernel, dim3(grid_for(px)), dim3(256), 0, st, I[i], Ul[i], Vl[i], vb, P, g.h, g.w);
-        hipLaunchKernelGGL(vr_deriv1_kernel, dim3(grid_for(px)), dim3(256), 0, st, vb, P, g.h, g.w);
-        hipLaunchKernelGGL(vr_deriv2_kernel, dim3(grid_for(px)), dim3(256), 0, st, vb, P, g.h, g.w);
-        for (int it = 0; it < VAR_ITERS; it++) {
-            hipLaunchKernelGGL(vr_weights_kernel, dim3(grid_for(px)), dim3(256), 0, st, vb, P, g.h, g.w, alpha2, eps2);
-            hipLaunchKernelGGL(vr_system_kernel, dim3(grid_for(px)), dim3(256), 0, st, vb, Ul[i], Vl[i], P, g.h, g.w, delta2, gamma2, zeta2, eps2);
-            const long long half = (long long)P * g.h * ((g.w + 1) / 2);
-            for (int s = 0; s < SOR_ITERS; s++) {
-                hipLaunchKernelGGL(vr_sor_kernel, dim3(grid_for(half)), dim3(256), 0, st, vb, P, g.h, g.w, 0, omega);
-                hipLaunchKernelGGL(vr_sor_kernel, dim3(grid_for(half)), dim3(256), 0, st, vb, P, g.h, g.w, 1, omega);
-            }
-            hipLaunchKernelGGL(vr_update_kernel, dim3(grid_for(px)), dim3(256), 0, st, vb, Ul[i], Vl[i], px, it == VAR_ITERS - 1 ? 1 : 0);
-        }
-        VSTAB_HIP(hipGetLastError());
+        LevelArgs la{};
+        la.I = I[i]; la.Sx = Sx; la.Sy = Sy; la.U = Ul[i]; la.V = Vl[i]; la.vb = vb;
+        la.P = P; la.h = g.h; la.w = g.w; la.ws = g.ws; la.hs = g.hs;
+        la.alpha2 = alpha2; la.delta2 = delta2; la.gamma2 = gamma2; la.zeta2 = zeta2; la.eps2 = eps2; la.omega = omega;
         if (i > FINEST) {
             const LevelGeom& d = G[i - 1];
-            const double sx = 1. / ((double)d.w / g.w), sy = 1. / ((double)d.h / g.h);
-            hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long long)P * d.h * d.w)), dim3(256), 0, st, Ul[i], Vl[i], Ul[i - 1], Vl[i - 1], P,
-                               g.h, g.w, d.h, d.w, sx, sy, 2.0f);
-            VSTAB_HIP(hipGetLastError());
+            la.nextU = Ul[i - 1]; la.nextV = Vl[i - 1]; la.nh = d.h; la.nw = d.w;
+            la.up_sx = 1. / ((double)d.w / g.w); la.up_sy = 1. / ((double)d.h / g.h);
         }
+        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(1024), 0, st, la);
+        VSTAB_HIP(hipGetLastError());
     }
-    // NOTE: vr_update on the last iteration wrote U = W + dW in place; earlier iterations must keep U = W.
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);
     const float mul = (float)(1 << FINEST);
     if (grid_flow) {

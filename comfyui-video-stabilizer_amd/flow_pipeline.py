@@ -128,8 +128,9 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
     base_mode = transform_mode
     working_size = hm._working_estimation_size(width, height)
     work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
-    matrices = [hm._rescale_transform_to_full(m, size, working_size) if working_size is not None else m
-                for m in work_mats]
+    matrices = np.stack(work_mats).astype(np.float32)
+    if working_size is not None:
+        matrices = hm.rescale_transforms_to_full(matrices, size, working_size)
     delta_params = np.stack([hm._matrix_to_params(m, base_mode) for m in matrices], axis=0)
 
     # ---- trajectory (F7-F8) --------------------------------------------------
@@ -186,9 +187,9 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
             "framing_mode='crop' (keep_fov crop solver, stabilizer_utils.py:448-837) is outside the hot path "
             "built so far; use 'crop_and_pad' or 'expand'.")
 
-    apply_matrices = [hm._params_to_matrix(d, base_mode) for d in diffs]
+    apply_matrices = np.stack([hm._params_to_matrix(d, base_mode) for d in diffs])
     output_size = size
-    mins, maxs = hm._compute_bounding_boxes(apply_matrices, width, height)
+    mins, maxs = hm.bounding_boxes_batched(apply_matrices, width, height)
     framing_meta: Dict[str, Any] = {
         "mode": framing_mode,
         "input_size": list(size),
@@ -202,7 +203,7 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
         off_x = width * 0.5 - (x0 + x1) * 0.5
         off_y = height * 0.5 - (y0 + y1) * 0.5
         shift = np.array([[1.0, 0.0, off_x], [0.0, 1.0, off_y], [0.0, 0.0, 1.0]], dtype=np.float32)
-        final_matrices = [shift @ m for m in apply_matrices]
+        final_matrices = list(np.matmul(shift, apply_matrices))
         framing_meta.update({
             "safe_region_origin": [x0, y0],
             "safe_region_size": [inter_w, inter_h],
@@ -211,7 +212,7 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
         })
     elif framing_mode == "expand":  # flow.py:530-533
         shift, output_size = hm._prepare_expand_transform(mins, maxs)
-        final_matrices = [shift @ m for m in apply_matrices]
+        final_matrices = list(np.matmul(shift, apply_matrices))
         framing_meta["expanded_size"] = list(output_size)
     else:
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
@@ -246,13 +247,9 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
     return FlowPlan(final_matrices, output_size, meta_head, framing_meta, estimated_motion, framing_mode, size, fps_effective)
 
 
-def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
-    """flow.py:583-640: padding statistics from the per-frame padded-pixel counts + the final dict."""
-    counts = np.asarray(pad_counts, dtype=np.int64)
-    pixels = np.float32(plan.output_size[0] * plan.output_size[1])
-    padded_ratios = [float(np.float32(c) / pixels) for c in counts]  # mask.mean() in float32 (flow.py:587)
-    framing_meta = dict(plan.framing_meta)
-    framing_meta["padding_detected"] = bool((counts > 0).any())
+def prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
+    """Everything of flow.py:596-640 that does not depend on the warped pixels (the heavy JSON part:
+    stabilization_warp + motion_meta).  Called while the warp kernel is still running."""
     h = plan.meta_head
     meta = {
         "frames": h["frames"],
@@ -264,7 +261,7 @@ def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
         "smooth": h["smooth"],
         "fps_requested": h["fps_requested"],
         "fps_effective": h["fps_effective"],
-        "framing": framing_meta,
+        "framing": dict(plan.framing_meta),
         "keep_fov_applied": h["keep_fov_applied"],
         "padding_color_rgb": h["padding_color_rgb"],
         "flow_backend": h["flow_backend"],
@@ -273,10 +270,25 @@ def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
             source_size=plan.source_size, output_size=plan.output_size, framing_mode=plan.framing_mode,
             applied_matrices=plan.final_matrices),
         "estimated_motion": plan.estimated_motion,
-        "padding_fraction_mean": float(np.mean(padded_ratios)),
-        "padding_fraction_max": float(np.max(padded_ratios)),
+        "padding_fraction_mean": None,
+        "padding_fraction_max": None,
     }
     return _attach_motion_meta(meta, plan.fps_effective)
+
+
+def complete_meta(meta: Dict[str, Any], plan: FlowPlan, pad_counts) -> Dict[str, Any]:
+    """flow.py:583-588, 596, 636-637: padding statistics from the per-frame padded-pixel counts."""
+    counts = np.asarray(pad_counts, dtype=np.int64)
+    pixels = np.float32(plan.output_size[0] * plan.output_size[1])
+    padded_ratios = (counts.astype(np.float32) / pixels).astype(np.float64)  # mask.mean() in float32 (flow.py:587)
+    meta["framing"]["padding_detected"] = bool((counts > 0).any())
+    meta["padding_fraction_mean"] = float(np.mean(padded_ratios))
+    meta["padding_fraction_max"] = float(np.max(padded_ratios))
+    return meta
+
+
+def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
+    return complete_meta(prepare_meta(plan), plan, pad_counts)
 
 
 def _stabilize_frames(
@@ -371,10 +383,10 @@ def _stabilize_frames(
     dst, mask, counts = ctx.warp_batch(
         device_frames, np.stack(plan.final_matrices).astype(np.float32), plan.output_size, interp="bilinear",
         border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
-    counts_host = counts.cpu().numpy().astype(np.int64)
+    meta = prepare_meta(plan)  # host JSON work overlaps the warp kernel
+    meta = complete_meta(meta, plan, counts.cpu().numpy())
     progress_done = _replay_progress(pbar, progress_done, total_frames, progress_total)
     check_interrupt()
-    meta = finish_meta(plan, counts_host)
     if keep_on_device:
         return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
     return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)

@@ -235,6 +235,17 @@ def _rescale_transform_to_full(matrix: np.ndarray, source_size, working_size) ->
     return (up @ matrix.astype(np.float64) @ down).astype(np.float32)
 
 
+def rescale_transforms_to_full(stack: np.ndarray, source_size, working_size) -> np.ndarray:
+    """Batched `_rescale_transform_to_full`: S and S^-1 are diagonal, so every entry of S^-1 @ M @ S is
+    one product chain fl(fl(inv_ii * M_ij) * s_jj) (the other dot-product terms are exact zeros); the
+    element-wise form below therefore gives the same bits as the 3x3 matmuls."""
+    sx = working_size[0] / float(source_size[0])
+    sy = working_size[1] / float(source_size[1])
+    down = np.array([sx, sy, 1.0], dtype=np.float64)
+    up = np.array([1.0 / sx, 1.0 / sy, 1.0], dtype=np.float64)
+    return ((up[None, :, None] * np.asarray(stack, dtype=np.float64)) * down[None, None, :]).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- parameter space (F6, F9)
 def _matrix_to_params(matrix: np.ndarray, base_mode: str) -> np.ndarray:
     """stabilizer_utils.py:300-324."""
@@ -281,6 +292,16 @@ def _compute_bounding_boxes(matrices: Sequence[np.ndarray], width: int, height: 
         mins.append([pts[0].min(), pts[1].min()])
         maxs.append([pts[0].max(), pts[1].max()])
     return np.array(mins), np.array(maxs)
+
+
+def bounding_boxes_batched(stack: np.ndarray, width: int, height: int):
+    """`_compute_bounding_boxes` for a stacked [N,3,3] array (one batched matmul)."""
+    corners = np.array([[0.0, 0.0, 1.0], [width, 0.0, 1.0], [0.0, height, 1.0], [width, height, 1.0]], dtype=np.float64).T
+    pts = np.matmul(stack, corners)
+    pts = pts / pts[:, 2:3, :]
+    mins = np.stack([pts[:, 0].min(axis=1), pts[:, 1].min(axis=1)], axis=1)
+    maxs = np.stack([pts[:, 0].max(axis=1), pts[:, 1].max(axis=1)], axis=1)
+    return mins, maxs
 
 
 def _min_content_ratio(mins: np.ndarray, maxs: np.ndarray, width: int, height: int) -> float:

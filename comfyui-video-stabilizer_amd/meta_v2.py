@@ -67,6 +67,33 @@ def _matrix_field(owner: str, entry: Any, position: int, key: str) -> np.ndarray
     return mat
 
 
+def _matrices_fast(owner: str, entries: list, key: str) -> Optional[np.ndarray]:
+    """All entries well-formed -> the stacked fp64 matrices after ONE batched finiteness / invertibility
+    check; None when anything is irregular (the caller then walks the entries one by one so that the
+    first offending entry produces exactly the reference's error message)."""
+    try:
+        for pos, entry in enumerate(entries):
+            if type(entry) is not dict or entry.get("index") != pos:
+                return None
+        stack = np.asarray([entry[key] for entry in entries], dtype=np.float64)
+    except (KeyError, TypeError, ValueError):
+        return None
+    if stack.ndim != 3 or stack.shape[1:] != (3, 3) or not np.isfinite(stack).all():
+        return None
+    try:
+        np.linalg.inv(stack)
+    except np.linalg.LinAlgError:
+        return None
+    return stack
+
+
+def _matrices_checked(owner: str, entries: list, key: str) -> List[np.ndarray]:
+    stack = _matrices_fast(owner, entries, key) if entries else None
+    if stack is not None:
+        return list(stack)
+    return [_matrix_field(owner, entry, pos, key) for pos, entry in enumerate(entries)]
+
+
 def validate_motion_meta(block: Dict[str, Any]) -> None:
     """motion_meta.py:62-100."""
     if not isinstance(block, dict):
@@ -101,8 +128,7 @@ def validate_motion_meta(block: Dict[str, Any]) -> None:
         raise ValueError(
             "motion_meta.frame_count mismatch: " f"frame_count is {count}, per_frame has {len(entries)} entry/entries."
         )
-    for pos, entry in enumerate(entries):
-        _matrix_field("motion_meta", entry, pos, "matrix")
+    _matrices_checked("motion_meta", entries, "matrix")
     if source == "generated_shake" and not isinstance(block.get("generator"), dict):
         raise ValueError("motion_meta.generator is required when source is 'generated_shake'.")
 
@@ -162,15 +188,15 @@ def motion_meta_from_stabilization_warp(warp_meta: Dict[str, Any], fps: float, s
 def applied_motion_meta_from_stabilization_warp(warp_meta: Dict[str, Any], fps: float, source: str) -> Dict[str, Any]:
     """As-applied motion (source -> stabilized) from the warp block (motion_meta.py:191-220)."""
     src, dst, entries = _warp_block_fields(warp_meta)
-    mats = [_matrix_field("stabilization_warp", entry, pos, "applied_matrix") for pos, entry in enumerate(entries)]
+    mats = _matrices_checked("stabilization_warp", entries, "applied_matrix")
     return build_motion_meta_v2(source=source, frame_count=len(mats), fps=fps, input_size=src, output_size=dst,
                                 matrices=mats)
 
 
 def _parse_block(block: Dict[str, Any]) -> MotionMeta:
     validate_motion_meta(block)
-    frames = [FrameTransform(index=pos, matrix=np.asarray(e["matrix"], dtype=np.float64))
-              for pos, e in enumerate(block["per_frame"])]
+    frames = [FrameTransform(index=pos, matrix=m)
+              for pos, m in enumerate(_matrices_checked("motion_meta", block["per_frame"], "matrix"))]
     gen = block.get("generator")
     return MotionMeta(
         source=str(block["source"]),

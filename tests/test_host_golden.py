@@ -189,3 +189,22 @@ def test_normalize_video_input_layouts(hm):
         with pytest.raises(ValueError) as info:
             hm._normalize_video_input([] if name == "empty" else {"x": 1})
         assert str(info.value) == err["message"]
+
+
+def test_batched_host_math_equals_per_item(hm):
+    """The vectorised forms used on the hot path give the same bits as the reference-shaped per-item helpers."""
+    rng = np.random.default_rng(3)
+    n = 300
+    th, sc = rng.uniform(-0.05, 0.05, n), rng.uniform(0.95, 1.05, n)
+    stack = np.tile(np.eye(3, dtype=np.float32), (n, 1, 1))
+    stack[:, 0, 0] = sc * np.cos(th); stack[:, 0, 1] = -sc * np.sin(th); stack[:, 1, 0] = sc * np.sin(th); stack[:, 1, 1] = sc * np.cos(th)
+    stack[:, :2, 2] = rng.uniform(-40, 40, (n, 2))
+    stack[::3, 2, :2] = rng.uniform(-1e-4, 1e-4, (n // 3, 2))
+    for src, work in (((1920, 1080), (960, 540)), ((3840, 2160), (960, 540)), ((1280, 720), (960, 540)), ((1000, 777), (960, 746))):
+        one = np.stack([hm._rescale_transform_to_full(m, src, work) for m in stack])
+        assert np.array_equal(hm.rescale_transforms_to_full(stack, src, work), one)
+    mins, maxs = hm._compute_bounding_boxes(list(stack), 1920, 1080)
+    bmins, bmaxs = hm.bounding_boxes_batched(stack, 1920, 1080)
+    assert np.array_equal(mins, bmins) and np.array_equal(maxs, bmaxs)
+    shift = np.array([[1, 0, 3.25], [0, 1, -7.5], [0, 0, 1]], np.float32)
+    assert np.array_equal(np.matmul(shift, stack), np.stack([shift @ m for m in stack]))
