@@ -19,6 +19,7 @@
 //   * nothing here is a contraction: no MFMA
 #include "vstab_internal.h"
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -223,11 +224,23 @@ __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ 
 }
 
 // ---- patch inverse search ------------------------------------------------------------------
+// 64-lane sum in the XOR-butterfly association (pairs, quads, 8-groups, 16-rows, row pairs, halves) done
+// with DPP row operations instead of LDS-path shuffles; every level adds the same two partial sums the
+// butterfly would, so the result is bit-identical to oracle/vo_dis.c's butterfly64().  Total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fetch(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
-    return v;
+    v += dpp_fetch<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_fetch<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_fetch<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_fetch<0x140, 0xf>(v);   // row_mirror
+    v += dpp_fetch<0x142, 0xa>(v);   // row_bcast15 into rows 1,3
+    v += dpp_fetch<0x143, 0xc>(v);   // row_bcast31 into rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 struct Bilin { int off; float w00, w01, w10, w11; };
@@ -263,21 +276,34 @@ struct PisArgs {
     int n, w, h, ws, hs, stripe_sz;
 };
 
-__global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
+// One 512-thread workgroup per frame pair: wave k runs stripe k (OpenCV's 8 fixed stripes).  The padded
+// I1 level image (<= 74 KB) and the pair's whole sparse flow field live in LDS, so the dependent chain
+// candidate -> bilinear window -> sums -> update never leaves the CU.
+__global__ __launch_bounds__(512) void pis_kernel(PisArgs a)
 {
-    extern __shared__ float lds[];  // [2][stripe_sz][ws]
-    const int pair = blockIdx.x >> 3, stripe = blockIdx.x & 7;
-    const int lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    extern __shared__ unsigned char pis_lds[];
+    const int pair = blockIdx.x, stripe = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int w = a.w, h = a.h, ws = a.ws, hs = a.hs;
-    const int w_ext = w + 2 * DIS_BORDER;
+    const int w_ext = w + 2 * DIS_BORDER, h_ext = h + 2 * DIS_BORDER;
+    const int img_bytes = (w_ext * h_ext + 15) & ~15;
+    unsigned char* lI1 = pis_lds;
+    float* lSx = reinterpret_cast<float*>(pis_lds + img_bytes);
+    float* lSy = lSx + hs * ws;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.Iext + (size_t)(pair + 1) * h_ext * w_ext);
+        const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+        const int nvec = aligned ? (w_ext * h_ext) / 16 : 0;
+        uint4* dst = reinterpret_cast<uint4*>(lI1);
+        for (int k = threadIdx.x; k < nvec; k += blockDim.x) dst[k] = src[k];
+        const unsigned char* sb = a.Iext + (size_t)(pair + 1) * h_ext * w_ext;
+        for (int k = nvec * 16 + threadIdx.x; k < w_ext * h_ext; k += blockDim.x) lI1[k] = sb[k];
+    }
+    __syncthreads();
     const int row_lo = min(stripe * a.stripe_sz, hs), row_hi = min((stripe + 1) * a.stripe_sz, hs);
-    if (row_lo >= row_hi) return;
-    float* lSx = lds;
-    float* lSy = lds + a.stripe_sz * ws;
     const uint8_t* I0 = a.I + (size_t)pair * h * w;
     const short* Ix = a.Ix + (size_t)pair * h * w;
     const short* Iy = a.Iy + (size_t)pair * h * w;
-    const uint8_t* I1e = a.Iext + (size_t)(pair + 1) * (h + 2 * DIS_BORDER) * w_ext;
     const size_t tplane = (size_t)a.n * hs * ws;
     const float* T = a.tensor + (size_t)pair * hs * ws;
     const float* U = a.U + (size_t)pair * h * w;
@@ -288,6 +314,7 @@ __global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
     const float nn = (float)(PSZ * PSZ);
     const int lane_off1 = r * w_ext + c;
 
+    if (row_lo < row_hi) {
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
         const int start_is = (iter == 0) ? row_lo : row_hi - 1;
@@ -298,22 +325,23 @@ __global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
             const int i = is * PSTR;
             for (int js = start_js; dir * js < dir * end_js; js += dir) {
                 const int j = js * PSTR;
-                const int lidx = (is - row_lo) * ws + js;
-                const size_t sidx = (size_t)is * ws + js;
+                const int sidx = is * ws + js;
                 const size_t poff = (size_t)(i + r) * w + j + c;
                 const float i0 = (float)I0[poff];
                 const float gx = (float)Ix[poff], gy = (float)Iy[poff];
+                const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
+                const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
                 float Sxv, Syv;
                 if (iter == 0) {
                     Sxv = U[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
                     Syv = V[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
                 } else {
-                    Sxv = lSx[lidx];
-                    Syv = lSy[lidx];
+                    Sxv = lSx[sidx];
+                    Syv = lSy[sidx];
                 }
 #define PATCH_DIFF(bw)                                                                                     \
     ({                                                                                                     \
-        const uint8_t* q_ = I1e + (bw).off + lane_off1;                                                    \
+        const unsigned char* q_ = lI1 + (bw).off + lane_off1;                                              \
         (bw).w00 * (float)q_[0] + (bw).w01 * (float)q_[1] + (bw).w10 * (float)q_[w_ext] +                  \
             (bw).w11 * (float)q_[w_ext + 1] - i0;                                                          \
     })
@@ -327,18 +355,16 @@ __global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
                 float min_SSD, cur_SSD;
                 SSD_AT(min_SSD, Sxv, Syv);
                 if (dir * js > dir * start_js) {
-                    const float nx = lSx[lidx - dir], ny = lSy[lidx - dir];
+                    const float nx = lSx[sidx - dir], ny = lSy[sidx - dir];
                     SSD_AT(cur_SSD, nx, ny);
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                 }
                 if (dir * is > dir * start_is) {
-                    const float nx = lSx[lidx - dir * ws], ny = lSy[lidx - dir * ws];
+                    const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
                     SSD_AT(cur_SSD, nx, ny);
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                 }
                 float cur_Ux = Sxv, cur_Uy = Syv;
-                const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
-                const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
                 float detH = txx * tyy - txy * txy;
                 if (__builtin_fabsf(detH) < DIS_EPS) detH = DIS_EPS;
                 const float invH11 = tyy / detH, invH12 = -txy / detH, invH22 = txx / detH;
@@ -364,17 +390,18 @@ __global__ __launch_bounds__(64) void pis_kernel(PisArgs a)
                     const double ddx = (double)(cur_Ux - Sxv), ddy = (double)(cur_Uy - Syv);
                     if (__builtin_sqrt(ddx * ddx + ddy * ddy) <= (double)PSZ) { Sxv = cur_Ux; Syv = cur_Uy; }
                 }
-                __syncthreads();
-                if (lane == 0) { lSx[lidx] = Sxv; lSy[lidx] = Syv; }
-                __syncthreads();
+                // the stripe is owned by this wave alone: LDS accesses of one wave execute in order
+                if (lane == 0) { lSx[sidx] = Sxv; lSy[sidx] = Syv; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
-    // write the stripe back
-    float* Sx = a.Sx + (size_t)pair * hs * ws + (size_t)row_lo * ws;
-    float* Sy = a.Sy + (size_t)pair * hs * ws + (size_t)row_lo * ws;
-    const int cnt = (row_hi - row_lo) * ws;
-    for (int k = lane; k < cnt; k += 64) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
+    }
+    __syncthreads();
+    float* Sx = a.Sx + (size_t)pair * hs * ws;
+    float* Sy = a.Sy + (size_t)pair * hs * ws;
+    for (int k = threadIdx.x; k < hs * ws; k += blockDim.x) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
 }
 
 // ---- per-pixel phase bodies (shared by every launch shape) -----------------------------------
@@ -520,24 +547,6 @@ __device__ __forceinline__ void vr_system_px(const VrBufs& b, const float* __res
     b.A11[q] = a11; b.A12[q] = a12; b.A22[q] = a22; b.b1[q] = B1; b.b2[q] = B2;
 }
 
-__device__ __forceinline__ void vr_sor_px(const VrBufs& b, long long q, int x, int y, int h, int w, float omega)
-{
-    const float wq = b.wgt[q];
-    const float wl = x > 0 ? b.wgt[q - 1] : 0.f, wu = y > 0 ? b.wgt[q - w] : 0.f;
-    const float dul = x > 0 ? b.dU[q - 1] : 0.f, dvl = x > 0 ? b.dV[q - 1] : 0.f;
-    const float dur = x + 1 < w ? b.dU[q + 1] : 0.f, dvr = x + 1 < w ? b.dV[q + 1] : 0.f;
-    const float duu = y > 0 ? b.dU[q - w] : 0.f, dvu = y > 0 ? b.dV[q - w] : 0.f;
-    const float dud = y + 1 < h ? b.dU[q + w] : 0.f, dvd = y + 1 < h ? b.dV[q + w] : 0.f;
-    const float sigmaU = wl * dul + wq * dur + wu * duu + wq * dud;
-    const float sigmaV = wl * dvl + wq * dvr + wu * dvu + wq * dvd;
-    const float a12 = b.A12[q];
-    float du = b.dU[q], dv = b.dV[q];
-    du += omega * ((sigmaU + b.b1[q] - dv * a12) / b.A11[q] - du);
-    dv += omega * ((sigmaV + b.b2[q] - du * a12) / b.A22[q] - dv);
-    b.dU[q] = du;
-    b.dV[q] = dv;
-}
-
 // ---- bilinear f32 resize (flow upsampling between levels), result scaled by `mul` ------------
 __device__ __forceinline__ void lin_coord(int d, double scale, int ssize, int& s0, float& f)
 {
@@ -581,15 +590,26 @@ struct LevelArgs {
     float* nextV;
     VrBufs vb;
     int P, h, w, ws, hs, nh, nw;
+    int tiles_x, tiles_y;   // SOR tiling (LDS temporal blocking)
+    int lds_plane;          // floats per LDS plane (max padded tile)
     double up_sx, up_sy;
     float alpha2, delta2, gamma2, zeta2, eps2, omega;
 };
 
-// One workgroup per frame pair runs densification, the whole variational refinement (5 fixed-point
-// iterations x 5 red-black SOR sweeps) and the x2 upsample to the next finer level.  The ~70 phases are
-// separated by workgroup barriers instead of kernel launches; the pair's planes stay in L2/Infinity Cache.
+constexpr int SOR_HALO = 2 * SOR_ITERS;   // one pixel of dependency per half-sweep
+constexpr int SOR_NPT = 5;                // owned pixels per thread and colour (tile <= 10240 px at 1024 threads)
+constexpr int SOR_TILE_CAP = 2 * SOR_NPT * 1024;
+
+// One workgroup per frame pair runs densification, the whole variational refinement and the x2 upsample
+// to the next finer level in ONE launch.  The red-black SOR sweeps of a fixed-point iteration are
+// temporally blocked: per tile, the smoothness weights and the increment (dU,dV) sit in LDS with a
+// 10-pixel halo (one pixel of dependency per half-sweep), the five linear-system coefficients of each
+// owned pixel sit in registers and never reach memory, all 10 half-sweeps run on-chip, and only the tile
+// interior is written back (double-buffered, because neighbouring tiles still need the old halo).
+// tempW of OpenCV (W + dW) is recomputed where needed instead of stored.
 __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
 {
+    extern __shared__ float vr_lds[];
     const int pair = blockIdx.x;
     const int h = a.h, w = a.w;
     const int npx = h * w;
@@ -599,38 +619,170 @@ __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
     const float* sx = a.Sx + (size_t)pair * a.hs * a.ws;
     const float* sy = a.Sy + (size_t)pair * a.hs * a.ws;
     const VrBufs& b = a.vb;
+    const float* __restrict__ U = a.U + base;
+    const float* __restrict__ V = a.V + base;
 #define FOR_PX(...)                                                         \
     for (int q_ = threadIdx.x; q_ < npx; q_ += blockDim.x) {                \
         const int y = q_ / w, x = q_ - y * w;                               \
         const long long t = base + q_;                                      \
+        (void)x; (void)y;                                                   \
         __VA_ARGS__;                                                        \
     }                                                                       \
     __syncthreads();
     FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
-    FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))
+    FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
     FOR_PX(vr_deriv1_px(b, t, x, y, h, w))
     FOR_PX(vr_deriv2_px(b, t, x, y, h, w))
-    const int half_w = (w + 1) >> 1;
-    const int nhalf = h * half_w;
+
+    float* lW = vr_lds;                    // smoothness weights
+    float* lU = vr_lds + a.lds_plane;      // dU
+    float* lV = vr_lds + 2 * a.lds_plane;  // dV
+    // increment ping-pong: (dU,dV) <-> (tU,tV) planes of the workspace
+    float* dIn_u = b.dU + base;  float* dIn_v = b.dV + base;
+    float* dOut_u = b.tU + base; float* dOut_v = b.tV + base;
+
     for (int it = 0; it < VAR_ITERS; it++) {
-        FOR_PX(vr_weights_px(b, t, x, y, h, w, a.alpha2, a.eps2))
-        FOR_PX(vr_system_px(b, a.U, a.V, t, x, y, h, w, a.delta2, a.gamma2, a.zeta2, a.eps2))
-        for (int s = 0; s < SOR_ITERS * 2; s++) {
-            const int color = s & 1;
-            for (int k_ = threadIdx.x; k_ < nhalf; k_ += blockDim.x) {
-                const int y = k_ / half_w;
-                const int x = 2 * (k_ - y * half_w) + ((y + color) & 1);
-                if (x < w) vr_sor_px(b, base + (long long)y * w + x, x, y, h, w, a.omega);
+        for (int tile = 0; tile < a.tiles_x * a.tiles_y; tile++) {
+            const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+            const int ix0 = (int)((long long)w * tx / a.tiles_x), ix1 = (int)((long long)w * (tx + 1) / a.tiles_x);
+            const int iy0 = (int)((long long)h * ty / a.tiles_y), iy1 = (int)((long long)h * (ty + 1) / a.tiles_y);
+            const int ox = max(ix0 - SOR_HALO, 0), oy = max(iy0 - SOR_HALO, 0);
+            const int lw = min(ix1 + SOR_HALO, w) - ox, lh = min(iy1 + SOR_HALO, h) - oy;
+            const int pw = lw + 2;                    // padded row length (1-px zero border)
+            const int pn = pw * (lh + 2);
+            // ---- stage 1: zero border, load the increment, compute the smoothness weights into LDS
+            for (int k = threadIdx.x; k < pn; k += blockDim.x) {
+                const int py = k / pw, px = k - py * pw;
+                const int lx = px - 1, ly = py - 1;
+                float wv = 0.f, du = 0.f, dv = 0.f;
+                if (lx >= 0 && lx < lw && ly >= 0 && ly < lh) {
+                    const int gx = ox + lx, gy = oy + ly;
+                    const int q = gy * w + gx;
+                    du = dIn_u[q]; dv = dIn_v[q];
+                    const int qr = (gx + 1 < w) ? q + 1 : q;
+                    const int qd = (gy + 1 < h) ? q + w : q;
+                    const float tu = U[q] + du, tv = V[q] + dv;
+                    const float tur = U[qr] + dIn_u[qr], tvr = V[qr] + dIn_v[qr];
+                    const float tud = U[qd] + dIn_u[qd], tvd = V[qd] + dIn_v[qd];
+                    const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
+                    wv = a.alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2);
+                }
+                lW[k] = wv; lU[k] = du; lV[k] = dv;
+            }
+            __syncthreads();
+            // ---- stage 2: linear system of the owned pixels -> registers
+            const int half_lw = (lw + 1) >> 1;
+            const int ncol = lh * half_lw;
+            float c11[2][SOR_NPT], c12[2][SOR_NPT], c22[2][SOR_NPT], cb1[2][SOR_NPT], cb2[2][SOR_NPT];
+            int cidx[2][SOR_NPT];
+#pragma unroll
+            for (int color = 0; color < 2; color++)
+#pragma unroll
+                for (int u = 0; u < SOR_NPT; u++) {
+                    const int k = threadIdx.x + u * 1024;
+                    cidx[color][u] = -1;
+                    if (k < ncol) {
+                        const int ly = k / half_lw;
+                        const int gy = oy + ly;
+                        const int lx = 2 * (k - ly * half_lw) + ((gy + ox + color) & 1);
+                        if (lx < lw) {
+                            const int gx = ox + lx;
+                            const int q = gy * w + gx;
+                            const int li = (ly + 1) * pw + lx + 1;
+                            cidx[color][u] = li;
+                            const long long t = base + q;
+                            const float Ix = b.Ix[t], Iy = b.Iy[t], Iz = b.Iz[t], Ixx = b.Ixx[t], Ixy = b.Ixy[t], Iyy = b.Iyy[t],
+                                        Ixz = b.Ixz[t], Iyz = b.Iyz[t];
+                            const float du = lU[li], dv = lV[li];
+                            float a11, a12, a22, B1, B2;
+                            {
+                                float derivNorm = Ix * Ix + Iy * Iy + a.zeta2;
+                                float Ik1z = Iz + Ix * du + Iy * dv;
+                                float weight = a.delta2 / __builtin_sqrtf(Ik1z * Ik1z / derivNorm + a.eps2);
+                                a11 = weight * (Ix * Ix / derivNorm) + a.zeta2;
+                                a12 = weight * (Ix * Iy / derivNorm);
+                                a22 = weight * (Iy * Iy / derivNorm) + a.zeta2;
+                                B1 = -weight * (Iz * Ix / derivNorm);
+                                B2 = -weight * (Iz * Iy / derivNorm);
+                                derivNorm = Ixx * Ixx + Ixy * Ixy + a.zeta2;
+                                float derivNorm2 = Iyy * Iyy + Ixy * Ixy + a.zeta2;
+                                float Ik1zx = Ixz + Ixx * du + Ixy * dv;
+                                float Ik1zy = Iyz + Ixy * du + Iyy * dv;
+                                weight = a.gamma2 / __builtin_sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + a.eps2);
+                                a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+                                a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+                                a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+                                B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+                                B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+                            }
+                            const bool red = ((gx + gy) & 1) == 0;
+                            const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
+                            const float wq = lW[li], uq = U[q], vq = V[q];
+                            float own_hu = 0, own_hv = 0, left_hu = 0, left_hv = 0, wl = 0;
+                            if (has_r) { own_hu = wq * (U[q + 1] - uq); own_hv = wq * (V[q + 1] - vq); }
+                            if (has_l) { wl = lW[li - 1]; left_hu = wl * (uq - U[q - 1]); left_hv = wl * (vq - V[q - 1]); }
+                            float own_vu = 0, own_vv = 0, up_vu = 0, up_vv = 0, wu = 0;
+                            if (has_d) { own_vu = wq * (U[q + w] - uq); own_vv = wq * (V[q + w] - vq); }
+                            if (has_u) { wu = lW[li - pw]; up_vu = wu * (uq - U[q - w]); up_vv = wu * (vq - V[q - w]); }
+                            if (red) {
+                                if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
+                                if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
+                                if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
+                                if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
+                            } else {
+                                if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
+                                if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
+                                if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
+                                if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
+                            }
+                            c11[color][u] = a11; c12[color][u] = a12; c22[color][u] = a22; cb1[color][u] = B1; cb2[color][u] = B2;
+                        }
+                    }
+                }
+            // NOTE: a left/up neighbour outside the tile (but inside the image) reads the zero border here; that
+            // only happens for halo pixels at the tile rim, whose values are never written back.
+            // ---- stage 3: 2*SOR_ITERS half-sweeps entirely in LDS
+            for (int s = 0; s < SOR_ITERS * 2; s++) {
+#pragma unroll
+                for (int color = 0; color < 2; color++) {
+                    if (color != (s & 1)) continue;
+#pragma unroll
+                    for (int u = 0; u < SOR_NPT; u++) {
+                        const int li = cidx[color][u];
+                        if (li >= 0) {
+                            const float wq = lW[li], wl = lW[li - 1], wu = lW[li - pw];
+                            const float sigmaU = wl * lU[li - 1] + wq * lU[li + 1] + wu * lU[li - pw] + wq * lU[li + pw];
+                            const float sigmaV = wl * lV[li - 1] + wq * lV[li + 1] + wu * lV[li - pw] + wq * lV[li + pw];
+                            float du = lU[li], dv = lV[li];
+                            du += a.omega * ((sigmaU + cb1[color][u] - dv * c12[color][u]) / c11[color][u] - du);
+                            dv += a.omega * ((sigmaV + cb2[color][u] - du * c12[color][u]) / c22[color][u] - dv);
+                            lU[li] = du;
+                            lV[li] = dv;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- stage 4: write the tile interior of the new increment
+            const int iw = ix1 - ix0, ih = iy1 - iy0;
+            for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
+                const int yy = k / iw, xx = k - yy * iw;
+                const int gx = ix0 + xx, gy = iy0 + yy;
+                const int li = (gy - oy + 1) * pw + (gx - ox + 1);
+                dOut_u[gy * w + gx] = lU[li];
+                dOut_v[gy * w + gx] = lV[li];
             }
             __syncthreads();
         }
-        const bool last = it == VAR_ITERS - 1;
-        FOR_PX({
-            const float u = a.U[t] + b.dU[t], v = a.V[t] + b.dV[t];
-            b.tU[t] = u; b.tV[t] = v;
-            if (last) { a.U[t] = u; a.V[t] = v; }
-        })
+        float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
+        tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
     }
+    // mergeCheckerboard(W, tempW): W + dW of the last fixed-point iteration
+    for (int q_ = threadIdx.x; q_ < npx; q_ += blockDim.x) {
+        a.U[base + q_] = U[q_] + dIn_u[q_];
+        a.V[base + q_] = V[q_] + dIn_v[q_];
+    }
+    __syncthreads();
 #undef FOR_PX
     if (a.nextU != nullptr) {
         const int nn = a.nh * a.nw;
@@ -804,9 +956,11 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
         pa.stripe_sz = (int)std::ceil(g.hs / 8.0);
-        const size_t lds_bytes = sizeof(float) * 2 * (size_t)pa.stripe_sz * g.ws;
-        VSTAB_REQUIRE(lds_bytes <= 64 * 1024, "vstab_dis_flow_batch: stripe of %d x %d patches does not fit LDS", pa.stripe_sz, g.ws);
-        hipLaunchKernelGGL(pis_kernel, dim3((unsigned)P * 8), dim3(64), lds_bytes, st, pa);
+        const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws;
+        VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
+        if (lds_bytes > 64 * 1024)
+            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(pis_kernel, dim3((unsigned)P), dim3(512), lds_bytes, st, pa);
         LevelArgs la{};
         la.I = I[i]; la.Sx = Sx; la.Sy = Sy; la.U = Ul[i]; la.V = Vl[i]; la.vb = vb;
         la.P = P; la.h = g.h; la.w = g.w; la.ws = g.ws; la.hs = g.hs;
@@ -816,7 +970,25 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
             la.nextU = Ul[i - 1]; la.nextV = Vl[i - 1]; la.nh = d.h; la.nw = d.w;
             la.up_sx = 1. / ((double)d.w / g.w); la.up_sy = 1. / ((double)d.h / g.h);
         }
-        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(1024), 0, st, la);
+        {   // smallest tiling whose padded tile fits SOR_TILE_CAP pixels (registers hold SOR_NPT pixels per colour)
+            int tx = 1, ty = 1;
+            auto tile_px = [&](int tx_, int ty_, int& padded) {
+                const int lw = std::min((g.w + tx_ - 1) / tx_ + 2 * SOR_HALO, g.w), lh = std::min((g.h + ty_ - 1) / ty_ + 2 * SOR_HALO, g.h);
+                padded = (lw + 2) * (lh + 2);
+                return ((lw + 1) / 2) * lh;   // pixels of one colour
+            };
+            int padded = 0;
+            while (tile_px(tx, ty, padded) > SOR_NPT * 1024) {
+                if ((g.w + tx - 1) / tx >= (g.h + ty - 1) / ty) tx++; else ty++;
+                VSTAB_REQUIRE(tx <= 64 && ty <= 64, "vstab_dis_flow_batch: cannot tile a %dx%d level", g.w, g.h);
+            }
+            la.tiles_x = tx; la.tiles_y = ty; la.lds_plane = (padded + 3) & ~3;
+        }
+        const size_t vr_lds_bytes = sizeof(float) * 3 * (size_t)la.lds_plane;
+        VSTAB_REQUIRE(vr_lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: SOR tile needs %zu B of LDS", vr_lds_bytes);
+        if (vr_lds_bytes > 64 * 1024)
+            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
+        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(1024), vr_lds_bytes, st, la);
         VSTAB_HIP(hipGetLastError());
     }
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);
