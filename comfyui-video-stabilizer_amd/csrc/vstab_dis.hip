@@ -276,28 +276,48 @@ struct PisArgs {
     int n, w, h, ws, hs, stripe_sz;
 };
 
-// One 512-thread workgroup per frame pair: wave k runs stripe k (OpenCV's 8 fixed stripes).  The padded
-// I1 level image (<= 74 KB) and the pair's whole sparse flow field live in LDS, so the dependent chain
+// Two 1024-thread workgroups per frame pair; each owns 4 of OpenCV's 8 fixed stripes and runs 4 waves per
+// stripe.  Inside a stripe the raster recurrence (left + top in the forward pass, right + bottom in the
+// backward pass) is kept exactly, but rows are software-pipelined along anti-diagonals: wave k of a stripe
+// handles rows k, k+4, ... and waits on an LDS progress counter of the row it depends on.  The padded I1
+// level image (<= 74 KB) and the block's sparse flow live in LDS, so the dependent chain
 // candidate -> bilinear window -> sums -> update never leaves the CU.
-__global__ __launch_bounds__(512) void pis_kernel(PisArgs a)
+constexpr int PIS_STRIPES_PER_BLOCK = 4;
+
+__device__ __forceinline__ void wait_progress(volatile int* counter, int need)
+{
+    // bounded spin (every wave of the workgroup is resident, so the producer always makes progress; the bound
+    // only turns a logic error into wrong output instead of a hung GPU)
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int PIS_ROW_WAVES>
+__global__ __launch_bounds__(256 * PIS_ROW_WAVES) void pis_kernel(PisArgs a)
 {
     extern __shared__ unsigned char pis_lds[];
-    const int pair = blockIdx.x, stripe = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const int stripe = half * PIS_STRIPES_PER_BLOCK + wave / PIS_ROW_WAVES, rlane = wave % PIS_ROW_WAVES;
     const int w = a.w, h = a.h, ws = a.ws, hs = a.hs;
     const int w_ext = w + 2 * DIS_BORDER, h_ext = h + 2 * DIS_BORDER;
     const int img_bytes = (w_ext * h_ext + 15) & ~15;
     unsigned char* lI1 = pis_lds;
-    float* lSx = reinterpret_cast<float*>(pis_lds + img_bytes);
+    float* lSx = reinterpret_cast<float*>(pis_lds + img_bytes);   // [hs][ws] (only this block's stripes are used)
     float* lSy = lSx + hs * ws;
+    int* done0 = reinterpret_cast<int*>(lSy + hs * ws);            // [hs] patches finished in the forward pass
+    int* done1 = done0 + hs;                                       // [hs] ... in the backward pass
     {
-        const uint4* src = reinterpret_cast<const uint4*>(a.Iext + (size_t)(pair + 1) * h_ext * w_ext);
-        const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+        const unsigned char* sb = a.Iext + (size_t)(pair + 1) * h_ext * w_ext;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(sb) & 15) == 0);
         const int nvec = aligned ? (w_ext * h_ext) / 16 : 0;
+        const uint4* src = reinterpret_cast<const uint4*>(sb);
         uint4* dst = reinterpret_cast<uint4*>(lI1);
         for (int k = threadIdx.x; k < nvec; k += blockDim.x) dst[k] = src[k];
-        const unsigned char* sb = a.Iext + (size_t)(pair + 1) * h_ext * w_ext;
         for (int k = nvec * 16 + threadIdx.x; k < w_ext * h_ext; k += blockDim.x) lI1[k] = sb[k];
+        for (int k = threadIdx.x; k < 2 * hs; k += blockDim.x) done0[k] = 0;
     }
     __syncthreads();
     const int row_lo = min(stripe * a.stripe_sz, hs), row_hi = min((stripe + 1) * a.stripe_sz, hs);
@@ -314,16 +334,19 @@ __global__ __launch_bounds__(512) void pis_kernel(PisArgs a)
     const float nn = (float)(PSZ * PSZ);
     const int lane_off1 = r * w_ext + c;
 
-    if (row_lo < row_hi) {
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
         const int start_is = (iter == 0) ? row_lo : row_hi - 1;
         const int end_is = (iter == 0) ? row_hi : row_lo - 1;
         const int start_js = (iter == 0) ? 0 : ws - 1;
         const int end_js = (iter == 0) ? ws : -1;
+        volatile int* done = (iter == 0) ? done0 : done1;
         for (int is = start_is; dir * is < dir * end_is; is += dir) {
+            if (((is - row_lo) % PIS_ROW_WAVES) != rlane) continue;   // rows of the stripe are dealt round-robin to its waves
+            const bool has_vert = dir * is > dir * start_is;           // a previously visited row exists in this pass
             const int i = is * PSTR;
-            for (int js = start_js; dir * js < dir * end_js; js += dir) {
+            int visited = 0;
+            for (int js = start_js; dir * js < dir * end_js; js += dir, visited++) {
                 const int j = js * PSTR;
                 const int sidx = is * ws + js;
                 const size_t poff = (size_t)(i + r) * w + j + c;
@@ -359,7 +382,8 @@ __global__ __launch_bounds__(512) void pis_kernel(PisArgs a)
                     SSD_AT(cur_SSD, nx, ny);
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                 }
-                if (dir * is > dir * start_is) {
+                if (has_vert) {
+                    wait_progress(done + (is - dir), visited + 1);   // the row above/below has finished this column
                     const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
                     SSD_AT(cur_SSD, nx, ny);
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
@@ -390,18 +414,23 @@ __global__ __launch_bounds__(512) void pis_kernel(PisArgs a)
                     const double ddx = (double)(cur_Ux - Sxv), ddy = (double)(cur_Uy - Syv);
                     if (__builtin_sqrt(ddx * ddx + ddy * ddy) <= (double)PSZ) { Sxv = cur_Ux; Syv = cur_Uy; }
                 }
-                // the stripe is owned by this wave alone: LDS accesses of one wave execute in order
-                if (lane == 0) { lSx[sidx] = Sxv; lSy[sidx] = Syv; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (lane == 0) {
+                    lSx[sidx] = Sxv;
+                    lSy[sidx] = Syv;
+                    __hip_atomic_store(const_cast<int*>(done + is), visited + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
         }
     }
-    }
     __syncthreads();
+    // this block's stripes only
+    const int blk_lo = min(half * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
+    const int blk_hi = min((half + 1) * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
     float* Sx = a.Sx + (size_t)pair * hs * ws;
     float* Sy = a.Sy + (size_t)pair * hs * ws;
-    for (int k = threadIdx.x; k < hs * ws; k += blockDim.x) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
+    for (int k = blk_lo * ws + threadIdx.x; k < blk_hi * ws; k += blockDim.x) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
 }
 
 // ---- per-pixel phase bodies (shared by every launch shape) -----------------------------------
@@ -956,11 +985,18 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
         pa.stripe_sz = (int)std::ceil(g.hs / 8.0);
-        const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws;
+        const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
-        if (lds_bytes > 64 * 1024)
-            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(pis_kernel, dim3((unsigned)P), dim3(512), lds_bytes, st, pa);
+        // rows of a stripe are pipelined over 4 waves only where a stripe has enough rows to pay for it
+        if (pa.stripe_sz >= 3) {
+            if (lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis_kernel<4>, dim3((unsigned)P * 2), dim3(1024), lds_bytes, st, pa);
+        } else {
+            if (lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis_kernel<1>, dim3((unsigned)P * 2), dim3(256), lds_bytes, st, pa);
+        }
         LevelArgs la{};
         la.I = I[i]; la.Sx = Sx; la.Sy = Sy; la.U = Ul[i]; la.V = Vl[i]; la.vb = vb;
         la.P = P; la.h = g.h; la.w = g.w; la.ws = g.ws; la.hs = g.hs;
