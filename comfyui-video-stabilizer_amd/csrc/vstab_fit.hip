@@ -364,11 +364,3 @@ extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, in
     return 0;
 }
 
-// Homography RANSAC lands in a follow-up translation unit; until then fail loudly.
-#ifndef VSTAB_HAVE_HOMOGRAPHY
-int vstab_fit_homography(vstab_ctx*, const float*, const int*, int, int, int, int, vstab_fit_record*)
-{
-    vstab_set_error("vstab_sample_fit_batch: perspective (homography) fit is not built yet");
-    return 98;
-}
-#endif

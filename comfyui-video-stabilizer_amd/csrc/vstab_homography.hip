@@ -1,0 +1,598 @@
+// vstab_homography.hip -- perspective branch of F5: cv2.findHomography(RANSAC, 2.5 px, 2000, 0.992)
+// (nodes/video_stabilizer_flow.py:162-175 of the reference), one 256-thread block per frame pair.
+//
+// OpenCV's pipeline is kept: 4-point minimal samples (same RNG stream, same duplicate / checkSubset
+// rejection, so the same samples are drawn), normalised DLT solved through the 9x9 symmetric Jacobi
+// eigen-decomposition, f32 reprojection-error test, adaptive iteration count; then a DLT over all inliers
+// and 10 Levenberg-Marquardt iterations on the 8 parameters.  Data-parallel mapping: one lane replays the
+// RNG and draws a batch of 16 samples, 16 lanes run the 16 Jacobi solves, all lanes score the batch in one
+// pass over the points, one lane replays the "best so far / update niters" loop.  The normal equations of
+// the refit and of every LM step are fp64 block reductions; the 8x8 solves run on one lane (Gaussian
+// elimination instead of OpenCV's eigen-solve: same solution to ~1e-13).
+#include "vstab_internal.h"
+#include <cmath>
+
+#define VSTAB_HAVE_HOMOGRAPHY 1
+
+namespace {
+
+constexpr int HT = 256;
+constexpr int HBATCH = 16;
+
+struct Rng { unsigned long long state; };
+__device__ __forceinline__ unsigned rng_next(Rng& r)
+{
+    r.state = (unsigned long long)(unsigned)r.state * 4164903690ULL + (unsigned)(r.state >> 32);
+    return (unsigned)r.state;
+}
+__device__ __forceinline__ int rng_uniform(Rng& r, int a, int b) { return a == b ? a : (int)(rng_next(r) % (unsigned)(b - a) + a); }
+
+__device__ int update_num_iters(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > 2.2250738585072014e-308 ? 1. - p : 2.2250738585072014e-308;
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)__builtin_rint(num / denom);
+}
+
+__device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, int step, int g, float& px, float& py, float& cx, float& cy)
+{
+    const int gy = g / gw, gx = g - gy * gw;
+    px = (float)(gx * step);
+    py = (float)(gy * step);
+    cx = px + F[(size_t)g * 2];
+    cy = py + F[(size_t)g * 2 + 1];
+}
+
+// JacobiImpl_ of OpenCV (core/src/lapack.cpp) for a symmetric n x n fp64 matrix; eigenvalues sorted descending,
+// eigenvectors are the rows of V.
+__device__ void jacobi_eigen(double* A, int n, double* W, double* V)
+{
+    const double eps = 2.220446049250313e-16;
+    int indR[9], indC[9];
+    int i, j, k, m;
+    double mv;
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) V[i * n + j] = 0;
+        V[i * n + i] = 1;
+    }
+    for (k = 0; k < n; k++) {
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) {
+            for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
+                double val = fabs(A[n * k + i]);
+                if (mv < val) mv = val, m = i;
+            }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
+                double val = fabs(A[n * i + k]);
+                if (mv < val) mv = val, m = i;
+            }
+            indC[k] = m;
+        }
+    }
+    const int maxIters = n * n * 30;
+    if (n > 1)
+        for (int iters = 0; iters < maxIters; iters++) {
+            for (k = 0, mv = fabs(A[indR[0]]), i = 1; i < n - 1; i++) {
+                double val = fabs(A[n * i + indR[i]]);
+                if (mv < val) mv = val, k = i;
+            }
+            int l = indR[k];
+            for (i = 1; i < n; i++) {
+                double val = fabs(A[n * indC[i] + i]);
+                if (mv < val) mv = val, k = indC[i], l = i;
+            }
+            double p = A[n * k + l];
+            if (fabs(p) <= eps) break;
+            double y = (W[l] - W[k]) * 0.5;
+            double t = fabs(y) + hypot(p, y);
+            double s = hypot(p, t);
+            double c = t / s;
+            s = p / s;
+            t = (p / t) * p;
+            if (y < 0) s = -s, t = -t;
+            A[n * k + l] = 0;
+            W[k] -= t;
+            W[l] += t;
+            double a0, b0;
+#define ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
+            for (i = 0; i < k; i++) ROT(A[n * i + k], A[n * i + l]);
+            for (i = k + 1; i < l; i++) ROT(A[n * k + i], A[n * i + l]);
+            for (i = l + 1; i < n; i++) ROT(A[n * k + i], A[n * l + i]);
+            for (i = 0; i < n; i++) ROT(V[n * k + i], V[n * l + i]);
+#undef ROT
+            for (j = 0; j < 2; j++) {
+                int idx = j == 0 ? k : l;
+                if (idx < n - 1) {
+                    for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
+                        double val = fabs(A[n * idx + i]);
+                        if (mv < val) mv = val, m = i;
+                    }
+                    indR[idx] = m;
+                }
+                if (idx > 0) {
+                    for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
+                        double val = fabs(A[n * i + idx]);
+                        if (mv < val) mv = val, m = i;
+                    }
+                    indC[idx] = m;
+                }
+            }
+        }
+    for (k = 0; k < n - 1; k++) {
+        m = k;
+        for (i = k + 1; i < n; i++)
+            if (W[m] < W[i]) m = i;
+        if (k != m) {
+            double tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+        }
+    }
+}
+
+// H from the normalisation parameters and LtL (HomographyEstimatorCallback::runKernel after the accumulation)
+__device__ void homography_from_ltl(double* LtL, double cmx, double cmy, double cMx, double cMy, double smx, double smy,
+                                    double sMx, double sMy, double* H)
+{
+    double W[9], V[81];
+    for (int j = 0; j < 9; j++)
+        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
+    jacobi_eigen(LtL, 9, W, V);
+    const double* H0 = V + 72;
+    const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    double T[9], R[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += invHnorm[r * 3 + k] * H0[k * 3 + c];
+            T[r * 3 + c] = s;
+        }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += T[r * 3 + k] * Hnorm2[k * 3 + c];
+            R[r * 3 + c] = s;
+        }
+    const double sc = 1. / R[8];
+    for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
+}
+
+__device__ bool homography_4pt(const float* M, const float* m, double* H)
+{
+    double LtL[81];
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    const int count = 4;
+    for (int i = 0; i < count; i++) { cmx += m[i * 2]; cmy += m[i * 2 + 1]; cMx += M[i * 2]; cMy += M[i * 2 + 1]; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; i++) {
+        smx += fabs(m[i * 2] - cmx); smy += fabs(m[i * 2 + 1] - cmy);
+        sMx += fabs(M[i * 2] - cMx); sMy += fabs(M[i * 2 + 1] - cMy);
+    }
+    const double eps = 2.220446049250313e-16;
+    if (fabs(smx) < eps || fabs(smy) < eps || fabs(sMx) < eps || fabs(sMy) < eps) return false;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    for (int i = 0; i < 81; i++) LtL[i] = 0;
+    for (int i = 0; i < count; i++) {
+        double x = (m[i * 2] - cmx) * smx, y = (m[i * 2 + 1] - cmy) * smy;
+        double X = (M[i * 2] - cMx) * sMx, Y = (M[i * 2 + 1] - cMy) * sMy;
+        double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; j++)
+            for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    homography_from_ltl(LtL, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
+    return true;
+}
+
+__device__ bool collinear(const float* p, int count)
+{
+    const int i = count - 1;
+    for (int j = 0; j < i; j++) {
+        double dx1 = p[j * 2] - p[i * 2], dy1 = p[j * 2 + 1] - p[i * 2 + 1];
+        for (int k = 0; k < j; k++) {
+            double dx2 = p[k * 2] - p[i * 2], dy2 = p[k * 2 + 1] - p[i * 2 + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+__device__ double det3pts(const float* p, int t0, int t1, int t2)
+{
+    const double a0 = p[t0 * 2], a1 = p[t0 * 2 + 1], a3 = p[t1 * 2], a4 = p[t1 * 2 + 1], a6 = p[t2 * 2], a7 = p[t2 * 2 + 1];
+    return a0 * (a4 * 1. - 1. * a7) - a1 * (a3 * 1. - 1. * a6) + 1. * (a3 * a7 - a4 * a6);
+}
+__device__ bool check_subset(const float* ms1, const float* ms2)
+{
+    if (collinear(ms1, 4) || collinear(ms2, 4)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; i++) negative += det3pts(ms1, tt[i][0], tt[i][1], tt[i][2]) * det3pts(ms2, tt[i][0], tt[i][1], tt[i][2]) < 0;
+    return negative == 0 || negative == 4;
+}
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const T total = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    __syncthreads();
+    return total;
+}
+
+// solve the symmetric n x n system A x = b (n <= 8) by Gaussian elimination with partial pivoting
+__device__ bool solve_sym(const double* A_in, const double* b, int n, double* x)
+{
+    double A[8][9];
+    for (int r = 0; r < n; r++) {
+        for (int c = 0; c < n; c++) A[r][c] = A_in[r * n + c];
+        A[r][n] = b[r];
+    }
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+        if (fabs(A[piv][col]) < 1e-300) return false;
+        if (piv != col) for (int k = 0; k <= n; k++) { const double t = A[piv][k]; A[piv][k] = A[col][k]; A[col][k] = t; }
+        for (int r = col + 1; r < n; r++) {
+            const double f = A[r][col] / A[col][col];
+            for (int k = col; k <= n; k++) A[r][k] -= f * A[col][k];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double v = A[r][n];
+        for (int k = r + 1; k < n; k++) v -= A[r][k] * x[k];
+        x[r] = v / A[r][r];
+    }
+    return true;
+}
+
+struct HArgs {
+    const float* grid_flow;
+    const int* vmap;
+    vstab_fit_record* out;
+    int pairs, gh, gw, step;
+};
+
+// residuals + (optionally) the normal equations of HomographyRefineCallback for parameters h[8] over the inliers
+// (inlier test against Hbest in f32, threshold thr).  Returns S = |r|^2; JtJ (36 upper entries) / Jtr (8) if wanted.
+__device__ double lm_accumulate(const HArgs& a, const float* F, const int* vmap, int nv, const float* Hbf, float thr, const double* h,
+                                bool want_jac, double* JtJ /*64*/, double* Jtr /*8*/, double* rinf, double* s_red)
+{
+    double acc[45];
+    for (int i = 0; i < 45; i++) acc[i] = 0;
+    double S = 0, rmax = 0;
+    for (int k = threadIdx.x; k < nv; k += HT) {
+        float px, py, cx, cy;
+        load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+        const float ww = 1.f / (Hbf[6] * px + Hbf[7] * py + 1.f);
+        const float ex = (Hbf[0] * px + Hbf[1] * py + Hbf[2]) * ww - cx;
+        const float ey = (Hbf[3] * px + Hbf[4] * py + Hbf[5]) * ww - cy;
+        if (!(ex * ex + ey * ey <= thr)) continue;
+        const double Mx = px, My = py;
+        double w = h[6] * Mx + h[7] * My + 1.;
+        w = fabs(w) > 2.220446049250313e-16 ? 1. / w : 0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * w;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * w;
+        const double r0 = xi - (double)cx, r1 = yi - (double)cy;
+        S += r0 * r0 + r1 * r1;
+        rmax = fmax(rmax, fmax(fabs(r0), fabs(r1)));
+        if (want_jac) {
+            const double J0[8] = {Mx * w, My * w, w, 0, 0, 0, -Mx * w * xi, -My * w * xi};
+            const double J1[8] = {0, 0, 0, Mx * w, My * w, w, -Mx * w * yi, -My * w * yi};
+            int idx = 0;
+            for (int p = 0; p < 8; p++)
+                for (int q = p; q < 8; q++) acc[idx++] += J0[p] * J0[q] + J1[p] * J1[q];
+            for (int p = 0; p < 8; p++) acc[36 + p] += J0[p] * r0 + J1[p] * r1;
+        }
+    }
+    S = block_sum(S, s_red);
+    // max via sum trick is not possible: reduce rmax with shuffles
+    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_down(rmax, s));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = rmax;
+    __syncthreads();
+    *rinf = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    __syncthreads();
+    if (want_jac) {
+        int idx = 0;
+        for (int p = 0; p < 8; p++)
+            for (int q = p; q < 8; q++) {
+                const double v = block_sum(acc[idx++], s_red);
+                JtJ[p * 8 + q] = v; JtJ[q * 8 + p] = v;
+            }
+        for (int p = 0; p < 8; p++) Jtr[p] = block_sum(acc[36 + p], s_red);
+    }
+    return S;
+}
+
+__global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
+{
+    __shared__ double s_model[HBATCH][9];
+    __shared__ float s_modelf[HBATCH][8];
+    __shared__ int s_ok[HBATCH];
+    __shared__ int s_idx[HBATCH][4];
+    __shared__ int s_cnt[HBATCH];
+    __shared__ double s_red[8];
+    __shared__ int s_redi[8];
+    __shared__ double s_best[9];
+    __shared__ double s_A[64], s_v[8], s_x[8], s_d[8];
+    __shared__ double s_lm[8];   // 0 lambda, 1 lc, 2 S, 3 flag
+    __shared__ int s_ctl[5];     // 0 done, 1 niters, 2 iter, 3 maxGood, 4 subset_failed
+    __shared__ Rng s_rng;
+
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int total = a.gh * a.gw;
+    const float* __restrict__ F = a.grid_flow + (size_t)pair * total * 2;
+    const int* __restrict__ vmap = a.vmap + (size_t)pair * total;
+    vstab_fit_record* out = a.out + (size_t)pair * 3 + VSTAB_MODE_PERSPECTIVE;
+    const int nv = a.out[(size_t)pair * 3].valid_points;
+    if (nv < 12) return;   // flow.py:153-154 (record stays "not computed")
+    const float thr = (float)(2.5 * 2.5);
+
+    if (tid == 0) { s_rng.state = ~0ULL; s_ctl[0] = 0; s_ctl[1] = 2000; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; }
+    __syncthreads();
+    while (true) {
+        if (tid == 0) {
+            Rng r = s_rng;
+            int failed = 0;
+            for (int c = 0; c < HBATCH && !failed; c++) {
+                bool found = false;
+                for (int attempt = 0; attempt < 10000 && !found; attempt++) {
+                    int idx[4];
+                    float ms1[8], ms2[8];
+                    for (int i = 0; i < 4; i++) {
+                        int v;
+                        bool dup;
+                        do {
+                            v = rng_uniform(r, 0, nv);
+                            dup = false;
+                            for (int q = 0; q < i; q++) dup |= (idx[q] == v);
+                        } while (dup);
+                        idx[i] = v;
+                        load_point(F, a.gw, a.step, vmap[v], ms1[i * 2], ms1[i * 2 + 1], ms2[i * 2], ms2[i * 2 + 1]);
+                    }
+                    if (check_subset(ms1, ms2)) {
+                        for (int i = 0; i < 4; i++) s_idx[c][i] = idx[i];
+                        found = true;
+                    }
+                }
+                if (!found) { failed = c + 1; for (int i = 0; i < 4; i++) s_idx[c][i] = -1; }
+            }
+            if (failed) for (int c = failed; c < HBATCH; c++) for (int i = 0; i < 4; i++) s_idx[c][i] = -1;
+            s_ctl[4] = failed;
+            s_rng = r;
+        }
+        __syncthreads();
+        if (tid < HBATCH) {
+            s_ok[tid] = 0;
+            s_cnt[tid] = 0;
+            if (s_idx[tid][0] >= 0) {
+                float ms1[8], ms2[8];
+                for (int i = 0; i < 4; i++) load_point(F, a.gw, a.step, vmap[s_idx[tid][i]], ms1[i * 2], ms1[i * 2 + 1], ms2[i * 2], ms2[i * 2 + 1]);
+                double H[9];
+                if (homography_4pt(ms1, ms2, H)) {
+                    for (int k = 0; k < 9; k++) s_model[tid][k] = H[k];
+                    for (int k = 0; k < 8; k++) s_modelf[tid][k] = (float)H[k];
+                    s_ok[tid] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        int cnt[HBATCH];
+#pragma unroll
+        for (int c = 0; c < HBATCH; c++) cnt[c] = 0;
+        for (int k = tid; k < nv; k += HT) {
+            float px, py, cx, cy;
+            load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+#pragma unroll
+            for (int c = 0; c < HBATCH; c++) {
+                const float ww = 1.f / (s_modelf[c][6] * px + s_modelf[c][7] * py + 1.f);
+                const float dx = (s_modelf[c][0] * px + s_modelf[c][1] * py + s_modelf[c][2]) * ww - cx;
+                const float dy = (s_modelf[c][3] * px + s_modelf[c][4] * py + s_modelf[c][5]) * ww - cy;
+                cnt[c] += (dx * dx + dy * dy <= thr) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HBATCH; c++) {
+            int v = cnt[c];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+            if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[c], v);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int niters = s_ctl[1], iter = s_ctl[2], maxGood = s_ctl[3];
+            bool stop = false;
+            for (int c = 0; c < HBATCH && iter < niters; c++, iter++) {
+                if (s_idx[c][0] < 0) { stop = true; break; }   // getSubset failed: iter == 0 -> no model, else break
+                if (!s_ok[c]) continue;                         // runKernel returned 0 models
+                const int good = s_cnt[c];
+                if (good > (maxGood > 3 ? maxGood : 3)) {
+                    for (int k = 0; k < 9; k++) s_best[k] = s_model[c][k];
+                    maxGood = good;
+                    niters = update_num_iters(0.992, (double)(nv - good) / nv, 4, niters);
+                }
+            }
+            s_ctl[1] = niters; s_ctl[2] = iter; s_ctl[3] = maxGood;
+            s_ctl[0] = (stop || iter >= niters) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_ctl[0]) break;
+    }
+    const int maxGood = s_ctl[3];
+    if (maxGood <= 0) {
+        if (tid == 0) out->computed = 1;
+        return;
+    }
+    // ---- refit: normalised DLT over all inliers of the best minimal model (runKernel on the compressed set)
+    float Hbf[8];
+    for (int k = 0; k < 8; k++) Hbf[k] = (float)s_best[k];
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int ninl = 0;
+    for (int k = tid; k < nv; k += HT) {
+        float px, py, cx, cy;
+        load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+        const float ww = 1.f / (Hbf[6] * px + Hbf[7] * py + 1.f);
+        const float ex = (Hbf[0] * px + Hbf[1] * py + Hbf[2]) * ww - cx;
+        const float ey = (Hbf[3] * px + Hbf[4] * py + Hbf[5]) * ww - cy;
+        if (ex * ex + ey * ey <= thr) { c0 += cx; c1 += cy; c2 += px; c3 += py; ninl++; }
+    }
+    double cmx = block_sum(c0, s_red), cmy = block_sum(c1, s_red), cMx = block_sum(c2, s_red), cMy = block_sum(c3, s_red);
+    ninl = block_sum(ninl, s_redi);
+    cmx /= ninl; cmy /= ninl; cMx /= ninl; cMy /= ninl;
+    c0 = c1 = c2 = c3 = 0;
+    for (int k = tid; k < nv; k += HT) {
+        float px, py, cx, cy;
+        load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+        const float ww = 1.f / (Hbf[6] * px + Hbf[7] * py + 1.f);
+        const float ex = (Hbf[0] * px + Hbf[1] * py + Hbf[2]) * ww - cx;
+        const float ey = (Hbf[3] * px + Hbf[4] * py + Hbf[5]) * ww - cy;
+        if (ex * ex + ey * ey <= thr) { c0 += fabs(cx - cmx); c1 += fabs(cy - cmy); c2 += fabs(px - cMx); c3 += fabs(py - cMy); }
+    }
+    double smx = block_sum(c0, s_red), smy = block_sum(c1, s_red), sMx = block_sum(c2, s_red), sMy = block_sum(c3, s_red);
+    const double deps = 2.220446049250313e-16;
+    const bool degenerate = fabs(smx) < deps || fabs(smy) < deps || fabs(sMx) < deps || fabs(sMy) < deps;
+    if (!degenerate) {
+        smx = ninl / smx; smy = ninl / smy; sMx = ninl / sMx; sMy = ninl / sMy;
+        double acc[45];
+        for (int i = 0; i < 45; i++) acc[i] = 0;
+        for (int k = tid; k < nv; k += HT) {
+            float px, py, cx, cy;
+            load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+            const float ww = 1.f / (Hbf[6] * px + Hbf[7] * py + 1.f);
+            const float ex = (Hbf[0] * px + Hbf[1] * py + Hbf[2]) * ww - cx;
+            const float ey = (Hbf[3] * px + Hbf[4] * py + Hbf[5]) * ww - cy;
+            if (!(ex * ex + ey * ey <= thr)) continue;
+            const double x = (cx - cmx) * smx, y = (cy - cmy) * smy;
+            const double X = (px - cMx) * sMx, Y = (py - cMy) * sMy;
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            int idx = 0;
+            for (int j = 0; j < 9; j++)
+                for (int q = j; q < 9; q++) acc[idx++] += Lx[j] * Lx[q] + Ly[j] * Ly[q];
+        }
+        __shared__ double s_LtL[81];
+        int idx = 0;
+        for (int j = 0; j < 9; j++)
+            for (int q = j; q < 9; q++) {
+                const double v = block_sum(acc[idx++], s_red);
+                if (tid == 0) s_LtL[j * 9 + q] = v;
+            }
+        __syncthreads();
+        if (tid == 0) {
+            double L[81], H[9];
+            for (int i = 0; i < 81; i++) L[i] = s_LtL[i];
+            homography_from_ltl(L, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
+            for (int i = 0; i < 9; i++) s_best[i] = H[i];
+        }
+        __syncthreads();
+    }
+    // ---- Levenberg-Marquardt, 10 iterations (LMSolverImpl::run, eps = FLT_EPSILON), parameters h[0..7]
+    double x[8];
+    for (int i = 0; i < 8; i++) x[i] = s_best[i];
+    double rinf;
+    double S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red);
+    __shared__ double s_D[8];
+    if (tid == 0) { for (int i = 0; i < 8; i++) s_D[i] = s_A[i * 8 + i]; s_lm[0] = 1.0; s_lm[1] = 0.75; }
+    __syncthreads();
+    const double Rlo = 0.25, Rhi = 0.75;
+    for (int iter = 0; iter < 10; iter++) {
+        if (tid == 0) {
+            double Ap[64];
+            for (int i = 0; i < 64; i++) Ap[i] = s_A[i];
+            for (int i = 0; i < 8; i++) Ap[i * 8 + i] += s_lm[0] * s_D[i];
+            double d[8];
+            if (!solve_sym(Ap, s_v, 8, d)) for (int i = 0; i < 8; i++) d[i] = 0;
+            for (int i = 0; i < 8; i++) { s_d[i] = d[i]; s_x[i] = x[i] - d[i]; }
+        }
+        __syncthreads();
+        double xd[8];
+        for (int i = 0; i < 8; i++) xd[i] = s_x[i];
+        double rinf_d;
+        const double Sd = lm_accumulate(a, F, vmap, nv, Hbf, thr, xd, false, nullptr, nullptr, &rinf_d, s_red);
+        if (tid == 0) {
+            double dS = 0, tdv = 0;
+            for (int i = 0; i < 8; i++) {
+                double s = 0;
+                for (int j = 0; j < 8; j++) s += s_A[i * 8 + j] * s_d[j];
+                dS += s_d[i] * (-s + 2 * s_v[i]);
+                tdv += s_d[i] * s_v[i];
+            }
+            const double R = (S - Sd) / (fabs(dS) > 2.220446049250313e-16 ? dS : 1);
+            double lambda = s_lm[0], lc = s_lm[1];
+            if (R > Rhi) {
+                lambda *= 0.5;
+                if (lambda < lc) lambda = 0;
+            } else if (R < Rlo) {
+                double nu = (Sd - S) / (fabs(tdv) > 2.220446049250313e-16 ? tdv : 1) + 2;
+                nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+                if (lambda == 0) {
+                    double maxval = 2.220446049250313e-16;
+                    for (int c = 0; c < 8; c++) {   // diagonal of A^-1, column by column
+                        double e[8], col[8];
+                        for (int i = 0; i < 8; i++) e[i] = (i == c);
+                        if (solve_sym(s_A, e, 8, col)) maxval = fmax(maxval, fabs(col[c]));
+                    }
+                    lambda = lc = 1. / maxval;
+                    nu *= 0.5;
+                }
+                lambda *= nu;
+            }
+            s_lm[0] = lambda; s_lm[1] = lc;
+            s_lm[3] = (Sd < S) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const bool accept = s_lm[3] != 0.0;
+        double dinf = 0;
+        for (int i = 0; i < 8; i++) dinf = fmax(dinf, fabs(s_d[i]));
+        if (accept) {
+            S = Sd;
+            for (int i = 0; i < 8; i++) x[i] = xd[i];
+            __syncthreads();
+            S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red);
+        }
+        __syncthreads();
+        if (!(iter + 1 < 10 && dinf >= 1.1920928955078125e-07 && rinf >= 1.1920928955078125e-07)) break;
+    }
+    // ---- record (flow.py:171-175: confidence = inliers/valid, residual uses the affine part of H only)
+    double res = 0;
+    for (int k = tid; k < nv; k += HT) {
+        float px, py, cx, cy;
+        load_point(F, a.gw, a.step, vmap[k], px, py, cx, cy);
+        const double X = px, Y = py;
+        res += fabs(X * x[0] + Y * x[1] + x[2] - (double)cx) + fabs(X * x[3] + Y * x[4] + x[5] - (double)cy);
+    }
+    res = block_sum(res, s_red);
+    if (tid == 0) {
+        out->computed = 1;
+        out->confidence = (double)maxGood / (double)nv;
+        if (out->confidence >= 0.15) {
+            for (int i = 0; i < 8; i++) out->matrix[i] = (float)x[i];
+            out->matrix[8] = 1.f;
+            out->residual = res / (2.0 * nv);
+            out->accepted = 1;
+        }
+    }
+}
+
+}  // namespace
+
+int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
+                         vstab_fit_record* d_out)
+{
+    HArgs a{grid_flow, vmap, d_out, pairs, gh, gw, step};
+    hipLaunchKernelGGL(homography_kernel, dim3((unsigned)pairs), dim3(HT), 0, ctx->stream, a);
+    VSTAB_HIP(hipGetLastError());
+    return 0;
+}
