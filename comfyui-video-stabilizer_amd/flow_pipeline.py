@@ -183,11 +183,17 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
                 "padding_fraction_max": 0.0,
             }
             return FlowPlan([], size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta)
-        raise NotImplementedError(
-            "framing_mode='crop' (keep_fov crop solver, stabilizer_utils.py:448-837) is outside the hot path "
-            "built so far; use 'crop_and_pad' or 'expand'.")
+        # flow.py:431-470: keep_fov solver, then the padding-free refinement
+        from .crop_solver import solve_crop
 
-    apply_matrices = np.stack([hm._params_to_matrix(d, base_mode) for d in diffs])
+        sol = solve_crop(ctx, base_mode, list(diffs), width, height, keep_fov_clamped,
+                         max(0.5, 0.02 * max(width, height)), interrupt_check=check_interrupt)
+        crop_solution = sol
+        apply_matrices = np.stack([np.asarray(m, dtype=np.float32) for m in sol["apply_matrices"]])
+        stabilization_scale = sol["scale"]
+    else:
+        crop_solution = None
+        apply_matrices = np.stack([hm._params_to_matrix(d, base_mode) for d in diffs])
     output_size = size
     mins, maxs = hm.bounding_boxes_batched(apply_matrices, width, height)
     framing_meta: Dict[str, Any] = {
@@ -196,7 +202,21 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
         "padding_color_rgb": rgb_list,
         "min_content_ratio": hm._min_content_ratio(mins, maxs, width, height),
     }
-    if framing_mode == "crop_and_pad":  # flow.py:500-529
+    if framing_mode == "crop":  # flow.py:485-499
+        final_matrices = [np.asarray(m, dtype=np.float32) for m in crop_solution["final_matrices"]]
+        framing_meta.update({
+            "keep_fov_status": crop_solution["status"],
+            "keep_fov_effective": crop_solution["keep_fov_effective"],
+            "crop_origin": crop_solution["crop_origin"],
+            "crop_size": crop_solution["crop_size"],
+            "actual_content_ratio": crop_solution["keep_fov_effective"],
+            "stabilization_scale": float(stabilization_scale),
+        })
+        if keep_fov_applied:
+            framing_meta["keep_fov_requested"] = keep_fov_clamped
+        if crop_solution["note"]:
+            framing_meta["keep_fov_note"] = crop_solution["note"]
+    elif framing_mode == "crop_and_pad":  # flow.py:500-529
         x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1]))
         x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
         inter_w, inter_h = max(1.0, x1 - x0), max(1.0, y1 - y0)
@@ -217,8 +237,10 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
     else:
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
 
+    effective_diffs = (np.array([hm._matrix_to_params(m, base_mode) for m in apply_matrices])
+                       if framing_mode == "crop" else diffs)  # flow.py:535-539
     stabilization_scale = float(np.clip(stabilization_scale, 0.0, 1.0))
-    effective_target_path = path + diffs
+    effective_target_path = path + effective_diffs
     meta_head = {
         "frames": total_frames,
         "transform_mode_requested": transform_mode,

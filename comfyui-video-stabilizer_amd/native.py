@@ -66,6 +66,8 @@ _SIGNATURES = {
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_sample_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_crop_analysis": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_trajectory": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
@@ -284,6 +286,19 @@ class Context:
                 }
             out.append(entry)
         return out
+
+    def crop_analysis(self, matrices, src_size, out_size):
+        """Nearest coverage of every frame -> (bbox [n,4] of the 3x3-closed coverage or -1, AND of all frames eroded 3x3)."""
+        m = np.ascontiguousarray(matrices, dtype=np.float32).reshape(-1, 9)
+        n = m.shape[0]
+        sw, sh = int(src_size[0]), int(src_size[1])
+        ow, oh = int(out_size[0]), int(out_size[1])
+        bbox = np.zeros((n, 4), np.int32)
+        common = np.zeros((oh, ow), np.uint8)
+        self.use_torch_stream()
+        _check(self.lib.vstab_crop_analysis(self.handle, m.ctypes.data, n, sh, sw, oh, ow, bbox.ctypes.data, common.ctypes.data),
+               "vstab_crop_analysis")
+        return bbox, common
 
     def trajectory(self, deltas, smooth, fps, strength, camera_lock):
         d = np.ascontiguousarray(deltas, dtype=np.float64)

@@ -136,6 +136,19 @@ typedef struct vstab_fit_record {
 int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw,
                            int step, int requested_mode, vstab_fit_record* results);
 
+/* ---- N1 (crop framing): coverage analysis for the keep_fov crop solver ---------
+ * Replaces the per-frame cv2 calls of nodes/stabilizer_utils.py:611-643
+ * (finalize_with_masks: warpPerspective(ones, NEAREST) > 0.5, dilate 3x3, erode 3x3, bounding box of
+ * the remaining content) and :763-787 (_refine_no_padding_crop: AND of the coverage masks of all
+ * frames, erode 3x3).  One pass over the n matrices serves both.
+ * matrices host [n,9] f32 (source -> output);  source src_h x src_w, output out_h x out_w.
+ * bbox     host [n,4] i32: x_min, y_min, x_max, y_max of the closed coverage, or -1,-1,-1,-1 if empty
+ * common   host [out_h*out_w] u8: 1 where every frame covers the pixel, after the 3x3 erosion
+ *          (pixels outside the image do not constrain the erosion, as cv2.erode's default border)
+ */
+int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w,
+                        int out_h, int out_w, int32_t* bbox, uint8_t* common);
+
 /* ---- F7 + F8: trajectory (prefix sum, box smoothing, strength blend), fp64 ---
  * Replaces nodes/video_stabilizer_flow.py:356-371 and
  * nodes/stabilizer_utils.py:361-383 (_smooth_path: moving average, edge padded,

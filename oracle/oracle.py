@@ -281,3 +281,15 @@ def find_homography(src, dst, thresh=2.5, max_iters=2000, confidence=0.992):
     lib().vo_find_homography_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
     ok = lib().vo_find_homography_ransac(src.ctypes.data, dst.ctypes.data, n, thresh, max_iters, confidence, m.ctypes.data, inl.ctypes.data)
     return (m.reshape(3, 3) if ok else None), inl
+
+
+# ---------------------------------------------------------------- crop coverage analysis
+def crop_analysis(matrices, src_size, out_size):
+    m = _f32(matrices).reshape(-1, 9)
+    n = m.shape[0]
+    sw, sh = int(src_size[0]), int(src_size[1])
+    ow, oh = int(out_size[0]), int(out_size[1])
+    bbox = np.zeros((n, 4), np.int32)
+    common = np.zeros((oh, ow), np.uint8)
+    lib().vo_crop_analysis(_ptr(m, C.c_float), n, sh, sw, oh, ow, _ptr(bbox, C.c_int32), _ptr(common, C.c_uint8))
+    return bbox, common

@@ -31,6 +31,9 @@ void vo_warp_blur_clip(const float* src, int n, int sh, int sw, const double* ma
                        int dw, int interp, const float* border, int subpix, double blur,
                        int samples, float* dst, float* mask);
 
+/* ---- crop coverage analysis (vo_crop.c) ---- */
+void vo_crop_analysis(const float* matrices, int n, int sh, int sw, int oh, int ow, int32_t* bbox, uint8_t* common);
+
 /* ---- gray + resize (vo_gray.c) ---- */
 void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray);
 void vo_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);

@@ -224,5 +224,5 @@ def test_flow_node_small_paths(api, ctx):
     assert out[2]["fps_effective"] == 24.0 and out[2]["fps_requested"] is None and out[2]["transform_mode_applied"] == "identity"
     out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop_and_pad", "similarity", True, 0.7, 0.2, 0.6, "#7F7F7F")
     assert out[2]["smooth"] == 0.85 and np.all(np.array(out[2]["estimated_motion"]["target_path"]) == 0.0)
-    with pytest.raises(NotImplementedError):
-        api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    assert out[2]["framing"]["mode"] == "crop" and float(out[1].max()) == 0.0
