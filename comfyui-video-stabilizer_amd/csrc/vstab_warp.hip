@@ -17,10 +17,6 @@
 namespace {
 
 constexpr int TILE_PX = 4;        // pixels per thread along x
-constexpr int TILE_TX = 32;       // threads along x
-constexpr int TILE_TY = 8;        // threads (rows) along y
-constexpr int TILE_W = TILE_TX * TILE_PX;
-constexpr int TILE_H = TILE_TY;
 constexpr int MAX_BLUR_SAMPLES = 33;
 
 struct WarpXform {   // per (frame, sample)
@@ -45,6 +41,7 @@ struct WarpArgs {
     int nxf_per_frame;  // sample matrices stored per frame (1 for a single-frame blur clip)
     float b0, b1, b2;   // border colour
     int vec_store;    // 1 if 16-B vector stores are legal (dw % 4 == 0, aligned bases)
+    int nt_store;     // experiment: nontemporal stores
 };
 
 __device__ __forceinline__ int clamp_round_i32(double v)
@@ -54,6 +51,14 @@ __device__ __forceinline__ int clamp_round_i32(double v)
     double m = (v < hi) ? v : hi;
     double r = (lo < m) ? m : lo;
     return (int)__builtin_rint(r);
+}
+
+// Round-half-even of an fp64 value known to satisfy |v| < 2^31: adding 1.5*2^52 leaves the integer in the
+// low 32 bits of the sum's bit pattern (one fp64 add instead of clamp + rint + convert).  Exactly what
+// cvRound gives for such values.
+__device__ __forceinline__ int round_small(double v)
+{
+    return (int)(unsigned)__double_as_longlong(v + 6755399441055744.0);
 }
 
 __device__ __forceinline__ int sat_short(int v)
@@ -201,9 +206,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + i;
 }
 
-template <int INTERP, int SUBPIX, bool BLUR, bool WITH_MASK>
+template <int INTERP, int SUBPIX, bool BLUR, bool WITH_MASK, int TILE_TX>
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 {
+    constexpr int TILE_W = TILE_TX * TILE_PX, TILE_H = 256 / TILE_TX;
     __shared__ unsigned s_cnt[4];
     const unsigned nblk = gridDim.x;
     const unsigned t = xcd_remap(blockIdx.x, nblk);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int frame = t / tiles_per_frame;
     const unsigned tr = t - frame * tiles_per_frame;
     const int tile_y = tr / a.tiles_x, tile_x = tr - tile_y * a.tiles_x;
-    const int tx = threadIdx.x & (TILE_TX - 1), ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x % TILE_TX, ty = threadIdx.x / TILE_TX;
     const int x0 = tile_x * TILE_W + tx * TILE_PX;
     const int y = tile_y * TILE_H + ty;
     const bool active = (y < a.dh) && (x0 < a.dw);
@@ -249,38 +255,58 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 #pragma unroll
                 for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
             }
+            // Fast path (the common case): affine map whose 1/32-px coordinates stay far inside the range where
+            // OpenCV's INT clamp and short saturation are no-ops (linear in x, so the two end pixels bound all 4).
+            bool small = false;
+            if (affine && !(SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR)) {
+                const double lim = 1.0e6;
+                const double d0 = (double)(x0 - xb), d3 = d0 + 3.0;
+                const double xa = (X0 + m0 * d0) * xf->wq, xz = (X0 + m0 * d3) * xf->wq;
+                const double ya = (Y0 + m3 * d0) * xf->wq, yz = (Y0 + m3 * d3) * xf->wq;
+                small = __builtin_fabs(xa) < lim && __builtin_fabs(xz) < lim && __builtin_fabs(ya) < lim && __builtin_fabs(yz) < lim;
+            }
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) {
                 if (p >= npx) continue;
                 const int x = x0 + p;
                 const double dx1 = (double)(x - xb);
                 const double Xn = X0 + m0 * dx1, Yn = Y0 + m3 * dx1;
-                double Wq, Wn;
-                if (affine) { Wq = xf->wq; Wn = xf->wn; }
-                else {
-                    const double W = W0 + m6 * dx1;
-                    Wq = (W != 0.0) ? 32.0 / W : 0.0;
-                    Wn = (W != 0.0) ? 1.0 / W : 0.0;
-                }
                 Px v;
-                if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
-                    const float w = x * mf[6] + y * mf[7] + mf[8];
-                    const float fsx = (x * mf[0] + y * mf[1] + mf[2]) / w;
-                    const float fsy = (x * mf[3] + y * mf[4] + mf[5]) / w;
-                    v = sample_exact(S, a.sh, a.sw, fsx, fsy, a.b0, a.b1, a.b2);
-                } else {
-                    const int X = clamp_round_i32(Xn * Wq);
-                    const int Y = clamp_round_i32(Yn * Wq);
+                float c = 0.f;
+                if (small) {
+                    const int X = round_small(Xn * xf->wq), Y = round_small(Yn * xf->wq);
                     v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
+                    if (WITH_MASK) {
+                        const int nx = round_small(Xn * xf->wn), ny = round_small(Yn * xf->wn);
+                        c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
+                    }
+                } else {
+                    double Wq, Wn;
+                    if (affine) { Wq = xf->wq; Wn = xf->wn; }
+                    else {
+                        const double W = W0 + m6 * dx1;
+                        Wq = (W != 0.0) ? 32.0 / W : 0.0;
+                        Wn = (W != 0.0) ? 1.0 / W : 0.0;
+                    }
+                    if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
+                        const float w = x * mf[6] + y * mf[7] + mf[8];
+                        const float fsx = (x * mf[0] + y * mf[1] + mf[2]) / w;
+                        const float fsy = (x * mf[3] + y * mf[4] + mf[5]) / w;
+                        v = sample_exact(S, a.sh, a.sw, fsx, fsy, a.b0, a.b1, a.b2);
+                    } else {
+                        const int X = clamp_round_i32(Xn * Wq);
+                        const int Y = clamp_round_i32(Yn * Wq);
+                        v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
+                    }
+                    if (WITH_MASK) {
+                        const int nx = sat_short(clamp_round_i32(Xn * Wn));
+                        const int ny = sat_short(clamp_round_i32(Yn * Wn));
+                        c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
+                    }
                 }
                 if (BLUR) { acc[p][0] += v.r; acc[p][1] += v.g; acc[p][2] += v.b; }
                 else { acc[p][0] = v.r; acc[p][1] = v.g; acc[p][2] = v.b; }
-                if (WITH_MASK) {
-                    const int nx = sat_short(clamp_round_i32(Xn * Wn));
-                    const int ny = sat_short(clamp_round_i32(Yn * Wn));
-                    const float c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
-                    if (BLUR) cov[p] += c; else cov[p] = c;
-                }
+                if (WITH_MASK) { if (BLUR) cov[p] += c; else cov[p] = c; }
             }
         }
     }
@@ -309,11 +335,17 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
         const size_t pix = ((size_t)frame * a.dh + y) * a.dw + x0;
         float* __restrict__ D = a.dst + pix * 3;
         if (a.vec_store) {
-            float4* D4 = reinterpret_cast<float4*>(D);
-            D4[0] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[1][0]);
-            D4[1] = make_float4(acc[1][1], acc[1][2], acc[2][0], acc[2][1]);
-            D4[2] = make_float4(acc[2][2], acc[3][0], acc[3][1], acc[3][2]);
-            if (WITH_MASK) *reinterpret_cast<float4*>(a.mask + pix) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4* D4 = reinterpret_cast<f4*>(D);
+            const f4 v0 = {acc[0][0], acc[0][1], acc[0][2], acc[1][0]}, v1 = {acc[1][1], acc[1][2], acc[2][0], acc[2][1]},
+                     v2 = {acc[2][2], acc[3][0], acc[3][1], acc[3][2]}, vm = {mk[0], mk[1], mk[2], mk[3]};
+            if (a.nt_store) {
+                __builtin_nontemporal_store(v0, D4); __builtin_nontemporal_store(v1, D4 + 1); __builtin_nontemporal_store(v2, D4 + 2);
+                if (WITH_MASK) __builtin_nontemporal_store(vm, reinterpret_cast<f4*>(a.mask + pix));
+            } else {
+                D4[0] = v0; D4[1] = v1; D4[2] = v2;
+                if (WITH_MASK) *reinterpret_cast<f4*>(a.mask + pix) = vm;
+            }
         } else {
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) {
@@ -337,21 +369,33 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 }
 
 template <int INTERP, int SUBPIX, bool BLUR>
-void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t st)
+void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t st, int tx)
 {
-    if (with_mask) hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, false>), dim3(grid), dim3(256), 0, st, a);
+#define LAUNCH_TX(TX)                                                                                              \
+    do {                                                                                                           \
+        if (with_mask) hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, true, TX>), dim3(grid), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, false, TX>), dim3(grid), dim3(256), 0, st, a);  \
+    } while (0)
+    if (tx == 16) LAUNCH_TX(16);
+    else if (tx == 64) LAUNCH_TX(64);
+    else if (tx == 8) LAUNCH_TX(8);
+    else LAUNCH_TX(32);
+#undef LAUNCH_TX
 }
 
 template <bool BLUR>
-int launch_warp(const WarpArgs& a, int interp, int subpix, bool with_mask, hipStream_t st)
+int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t st)
 {
+    const int tx = getenv("VSTAB_WARP_TX") ? atoi(getenv("VSTAB_WARP_TX")) : 32;
+    a.nt_store = getenv("VSTAB_WARP_NT") ? atoi(getenv("VSTAB_WARP_NT")) : 0;
+    a.tiles_x = (a.dw + tx * TILE_PX - 1) / (tx * TILE_PX);
+    a.tiles_y = (a.dh + 256 / tx - 1) / (256 / tx);
     const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
     VSTAB_REQUIRE(blocks > 0 && blocks < 0x7fffffffULL, "warp: grid of %llu blocks is out of range", blocks);
     const unsigned grid = (unsigned)blocks;
-    if (interp == VSTAB_INTERP_BICUBIC) launch_mask<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st);
-    else if (subpix == VSTAB_SUBPIX_EXACT) launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT, BLUR>(a, with_mask, grid, st);
-    else launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st);
+    if (interp == VSTAB_INTERP_BICUBIC) launch_mask<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st, tx);
+    else if (subpix == VSTAB_SUBPIX_EXACT) launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT, BLUR>(a, with_mask, grid, st, tx);
+    else launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st, tx);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }
@@ -389,8 +433,6 @@ void fill_geometry(WarpArgs& a, int n, int sh, int sw, int dh, int dw, const flo
     int bw0 = BLOCK_SZ * BLOCK_SZ / bh0 < dw ? BLOCK_SZ * BLOCK_SZ / bh0 : dw;
     a.bw0 = bw0;
     a.bw0_pow2 = (bw0 & (bw0 - 1)) == 0;
-    a.tiles_x = (dw + TILE_W - 1) / TILE_W;
-    a.tiles_y = (dh + TILE_H - 1) / TILE_H;
     a.b0 = border[0]; a.b1 = border[1]; a.b2 = border[2];
     const bool aligned = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
     a.vec_store = ((dw & 3) == 0 && aligned) ? 1 : 0;
