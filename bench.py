@@ -128,7 +128,8 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU (BASELINE configs[1]: 256)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the clip timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -147,8 +148,12 @@ def main() -> None:
 
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     import __graft_entry__ as graft
@@ -170,7 +175,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def step():
-        if world == 1:
+        if not use_dist:
             context = hm.VideoContext([None] * n_local, hm.FrameAdapter(np.dtype(np.float32), False, "0_1", "torch", False),
                                       w, h, 3, None, "sequence", {}, batch=frames)
             res = fp._stabilize_frames(context, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
@@ -179,7 +184,7 @@ def main() -> None:
         return vd.stabilize_sharded(ctx, frames, total, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +202,7 @@ def main() -> None:
         del out
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -253,7 +258,7 @@ def main() -> None:
             sample = frames[: min(args.cpu_frames, n_local)].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(sample, threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

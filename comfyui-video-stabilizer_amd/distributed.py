@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import host_math as hm
-from .flow_pipeline import estimate_transitions, finish_meta, plan_stabilization
+from .flow_pipeline import complete_meta, estimate_transitions, plan_stabilization, prepare_meta
 
 MODE_NAMES = ("translation", "similarity", "perspective")
 _REC_WIDTH = 16  # 9 matrix + confidence + residual + accepted + computed + valid + total + pad
@@ -154,7 +154,8 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     mats = np.stack(plan.final_matrices[start:end]).astype(np.float32)
     dst, mask, counts = ctx.warp_batch(own, mats, plan.output_size, interp="bilinear", border=hm.border_value(padding_rgb),
                                        want_mask=True, want_count=True)
+    meta = prepare_meta(plan)  # host JSON work overlaps this rank's warp kernel
     frame_counts = [shard_range(total_frames, world, r)[1] - shard_range(total_frames, world, r)[0] for r in range(world)]
     all_counts = _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), frame_counts, group=group, device=dev)
-    meta = finish_meta(plan, all_counts.reshape(-1))
+    meta = complete_meta(meta, plan, all_counts.reshape(-1))
     return dst, mask, meta
