@@ -25,8 +25,6 @@ import numpy as np
 from . import host_math as hm
 from .flow_pipeline import complete_meta, estimate_transitions, plan_stabilization, prepare_meta
 
-MODE_NAMES = ("translation", "similarity", "perspective")
-_REC_WIDTH = 16  # 9 matrix + confidence + residual + accepted + computed + valid + total + pad
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -34,44 +32,6 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     base, extra = divmod(int(total), int(world))
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
-
-
-def pack_records(records: Sequence[Dict[str, Any]], rows: int) -> np.ndarray:
-    """List of per-transition candidate dicts -> dense [rows, 3, 16] float64 (unused rows zero)."""
-    out = np.zeros((rows, 3, _REC_WIDTH), np.float64)
-    for i, entry in enumerate(records):
-        for mi, name in enumerate(MODE_NAMES):
-            cand = entry.get(name)
-            if cand is None:
-                continue
-            out[i, mi, :9] = np.asarray(cand["matrix"], np.float64).reshape(9)
-            out[i, mi, 9] = cand["confidence"]
-            out[i, mi, 10] = cand["residual"]
-            out[i, mi, 11] = 1.0 if cand["accepted"] else 0.0
-            out[i, mi, 12] = 1.0
-            out[i, mi, 13] = cand.get("valid_points", 0)
-            out[i, mi, 14] = cand.get("total_points", 0)
-    return out
-
-
-def unpack_records(packed: np.ndarray, count: int) -> List[Dict[str, Any]]:
-    out: List[Dict[str, Any]] = []
-    for i in range(count):
-        entry: Dict[str, Any] = {}
-        for mi, name in enumerate(MODE_NAMES):
-            row = packed[i, mi]
-            if row[12] == 0.0:
-                continue
-            entry[name] = {
-                "matrix": row[:9].astype(np.float32).reshape(3, 3),
-                "confidence": float(row[9]),
-                "residual": float(row[10]),
-                "accepted": bool(row[11]),
-                "valid_points": int(row[13]),
-                "total_points": int(row[14]),
-            }
-        out.append(entry)
-    return out
 
 
 def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=None) -> np.ndarray:
@@ -101,18 +61,23 @@ def transition_counts(total_frames: int, world: int) -> List[int]:
     return out
 
 
-def gather_fit_records(local_records: Sequence[Dict[str, Any]], total_frames: int, group=None, device=None):
-    """The one data-path collective of the sharded Flow pipeline."""
+def gather_fit_records(local_table, total_frames: int, group=None, device=None):
+    """The one data-path collective of the sharded Flow pipeline: all-gather of the raw fit-record table
+    (72 B per pair and mode).  Accepts the structured table or the list-of-dicts form."""
     import torch.distributed as dist
 
+    from . import native
+
+    if not isinstance(local_table, np.ndarray):
+        local_table = native.fit_table_from_dicts(local_table)
     world = dist.get_world_size(group)
     counts = transition_counts(total_frames, world)
     rank = dist.get_rank(group)
-    if len(local_records) != counts[rank]:
-        raise ValueError(f"rank {rank} produced {len(local_records)} transitions, expected {counts[rank]}")
-    packed = pack_records(local_records, max(max(counts), 1))[: counts[rank]]
-    full = _gather_rows(packed, counts, group=group, device=device)
-    return unpack_records(full, full.shape[0])
+    if local_table.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} produced {local_table.shape[0]} transitions, expected {counts[rank]}")
+    raw = np.ascontiguousarray(local_table).view(np.uint8).reshape(local_table.shape[0], 3 * native.FIT_DTYPE.itemsize)
+    full = _gather_rows(raw, counts, group=group, device=device)
+    return np.ascontiguousarray(full).view(native.FIT_DTYPE).reshape(-1, 3)
 
 
 def collective_device(ctx=None):
@@ -144,7 +109,10 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     dev = collective_device(ctx)
 
     working_size = hm._working_estimation_size(width, height)
-    local_records = estimate_transitions(ctx, local_frames, working_size, transform_mode) if local_frames.shape[0] >= 2 else []
+    from . import native
+
+    local_records = (estimate_transitions(ctx, local_frames, working_size, transform_mode) if local_frames.shape[0] >= 2
+                     else np.zeros((0, 3), native.FIT_DTYPE))
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)
     plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
                               keep_fov, padding_rgb, fps_effective, fps_requested)

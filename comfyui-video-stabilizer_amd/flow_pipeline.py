@@ -14,6 +14,7 @@ The host keeps only what is sequential or scalar in the reference (flow.py:324-3
 
 from __future__ import annotations
 
+import gc
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -22,14 +23,23 @@ import numpy as np
 from . import host_math as hm
 from . import native
 from .comfy_compat import ProgressBar, check_interrupt
-from .meta_v2 import applied_motion_meta_from_stabilization_warp
+from .meta_v2 import applied_motion_meta_from_arrays, applied_motion_meta_from_stabilization_warp
 
 SAMPLE_STEP = 8  # flow.py:138
-_FALLBACK_CHAIN = {
-    "perspective": ("perspective", "similarity", "translation"),
-    "similarity": ("similarity", "translation"),
-    "translation": ("translation",),
-}
+
+
+class _gc_paused:
+    """The plan / meta builders create tens of thousands of small Python objects per clip; a generational GC
+    pass landing in the middle costs more than the work itself.  Collection is only postponed, not skipped."""
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+        return False
 
 
 def _attach_motion_meta(meta: Dict[str, Any], fps: float) -> Dict[str, Any]:
@@ -54,29 +64,51 @@ def _replay_progress(pbar, done: int, count: int, total: int, stride: int = 10) 
     return done
 
 
-def select_transitions(fit_records: List[Dict[str, Any]], requested_mode: str):
+_MODE_INDEX = {"translation": 0, "similarity": 1, "perspective": 2}
+_MODE_NAME = ("translation", "similarity", "perspective")
+
+
+def select_transitions(fit_records, requested_mode: str):
     """Sequential 'sticky active_mode' walk over the per-pair candidate fits (flow.py:324-339, 153-210).
 
-    Returns (matrices f32 @ working resolution, modes, confidences, residuals, final active mode)."""
-    active = requested_mode
-    mats, modes, confs, resids = [], [], [], []
-    for entry in fit_records:
-        chosen = None
-        if entry:  # empty entry: fewer than 12 finite samples (flow.py:153-154)
-            for mode in _FALLBACK_CHAIN[active]:
-                cand = entry.get(mode)
-                if cand is not None and cand["accepted"]:
-                    chosen = (cand["matrix"], mode, cand["confidence"], cand["residual"])
-                    break
-        if chosen is None:
-            chosen = (np.eye(3, dtype=np.float32), "translation", 0.0, 0.0)
-        if chosen[1] != active:
-            active = chosen[1]
-        mats.append(chosen[0])
-        modes.append(chosen[1])
-        confs.append(float(chosen[2]))
-        resids.append(float(chosen[3]))
-    return mats, modes, confs, resids, active
+    `fit_records`: structured table [P,3] (native.FIT_DTYPE) or the equivalent list of dicts.
+    Returns (matrices f32 [P,3,3] @ working resolution, modes, confidences, residuals, final active mode)."""
+    table = fit_records if isinstance(fit_records, np.ndarray) else native.fit_table_from_dicts(fit_records)
+    pairs = table.shape[0]
+    usable = (table["computed"] != 0) & (table["accepted"] != 0)   # [P,3], mode index 0..2
+    active = _MODE_INDEX[requested_mode]
+    chosen = np.empty(pairs, dtype=np.int64)
+    p = 0
+    while p < pairs:
+        # the active mode keeps winning until the first pair whose fit at that mode was rejected
+        ok = usable[p:, active]
+        run = int(ok.size if ok.all() else np.argmin(ok))
+        chosen[p:p + run] = active
+        p += run
+        if p >= pairs:
+            break
+        pick = -1
+        for m in range(active - 1, -1, -1):   # perspective -> similarity -> translation
+            if usable[p, m]:
+                pick = m
+                break
+        chosen[p] = pick
+        # no candidate at all (fewer than 12 finite samples, flow.py:153-154): identity, reported as "translation"
+        active = pick if pick >= 0 else 0
+        p += 1
+    idx = chosen
+    safe = np.where(idx >= 0, idx, 0)
+    rows = table[np.arange(pairs), safe]
+    mats = rows["matrix"].reshape(pairs, 3, 3).astype(np.float32)
+    confs = rows["confidence"].astype(np.float64)
+    resids = rows["residual"].astype(np.float64)
+    missing = idx < 0
+    if missing.any():
+        mats[missing] = np.eye(3, dtype=np.float32)
+        confs[missing] = 0.0
+        resids[missing] = 0.0
+    modes = [_MODE_NAME[m] if m >= 0 else "translation" for m in chosen.tolist()]
+    return mats, modes, confs.tolist(), resids.tolist(), _MODE_NAME[active]
 
 
 def estimate_transitions(ctx, device_frames, working_size, transform_mode: str):
@@ -118,7 +150,12 @@ class FlowPlan:
     bypass_meta: Optional[Dict[str, Any]] = None
 
 
-def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
+def plan_stabilization(*args, **kwargs) -> "FlowPlan":
+    with _gc_paused():
+        return _plan_stabilization(*args, **kwargs)
+
+
+def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
                        keep_fov, padding_rgb, fps_effective, fps_requested) -> FlowPlan:
     """flow.py:324-546 for a whole clip: sticky-mode selection, parameter deltas, trajectory (HIP fp64),
     framing geometry.  `fit_records` covers all N-1 transitions of the clip."""
@@ -128,10 +165,10 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
     base_mode = transform_mode
     working_size = hm._working_estimation_size(width, height)
     work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
-    matrices = np.stack(work_mats).astype(np.float32)
+    matrices = np.asarray(work_mats, dtype=np.float32).reshape(-1, 3, 3)
     if working_size is not None:
         matrices = hm.rescale_transforms_to_full(matrices, size, working_size)
-    delta_params = np.stack([hm._matrix_to_params(m, base_mode) for m in matrices], axis=0)
+    delta_params = hm.matrices_to_params(matrices, base_mode)
 
     # ---- trajectory (F7-F8) --------------------------------------------------
     strength = float(np.clip(strength, 0.0, 1.0))
@@ -193,7 +230,7 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
         stabilization_scale = sol["scale"]
     else:
         crop_solution = None
-        apply_matrices = np.stack([hm._params_to_matrix(d, base_mode) for d in diffs])
+        apply_matrices = hm.params_to_matrices(diffs, base_mode)
     output_size = size
     mins, maxs = hm.bounding_boxes_batched(apply_matrices, width, height)
     framing_meta: Dict[str, Any] = {
@@ -237,8 +274,7 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
     else:
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
 
-    effective_diffs = (np.array([hm._matrix_to_params(m, base_mode) for m in apply_matrices])
-                       if framing_mode == "crop" else diffs)  # flow.py:535-539
+    effective_diffs = hm.matrices_to_params(apply_matrices, base_mode) if framing_mode == "crop" else diffs  # flow.py:535-539
     stabilization_scale = float(np.clip(stabilization_scale, 0.0, 1.0))
     effective_target_path = path + effective_diffs
     meta_head = {
@@ -256,23 +292,24 @@ def plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, trans
         "flow_backend": flow_backend,
         "flow_fallback_reason": flow_fallback_reason,
     }
-    estimated_motion = {
-        "per_transition": [
-            {"index": i, "mode": mode, "confidence": conf, "residual": resid,
-             "matrix": matrices[i].astype(np.float32).tolist()}
-            for i, (mode, conf, resid) in enumerate(zip(modes_used, confidences, residuals))
-        ],
-        "path": path.tolist(),
-        "target_path": target_path.tolist(),
-        "target_path_effective": effective_target_path.tolist(),
+    estimated_motion = {   # arrays; turned into JSON lists by prepare_meta (off the critical path)
+        "modes": modes_used, "confidences": confidences, "residuals": residuals, "matrices": matrices,
+        "path": path, "target_path": target_path, "target_path_effective": effective_target_path,
     }
     return FlowPlan(final_matrices, output_size, meta_head, framing_meta, estimated_motion, framing_mode, size, fps_effective)
 
 
 def prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
+    with _gc_paused():
+        return _prepare_meta(plan)
+
+
+def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
     """Everything of flow.py:596-640 that does not depend on the warped pixels (the heavy JSON part:
     stabilization_warp + motion_meta).  Called while the warp kernel is still running."""
     h = plan.meta_head
+    em = plan.estimated_motion
+    final_stack = np.asarray(plan.final_matrices, dtype=np.float32).reshape(-1, 3, 3)
     meta = {
         "frames": h["frames"],
         "transform_mode_requested": h["transform_mode_requested"],
@@ -290,11 +327,24 @@ def prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
         "flow_fallback_reason": h["flow_fallback_reason"],
         "stabilization_warp": hm._build_stabilization_warp_meta(
             source_size=plan.source_size, output_size=plan.output_size, framing_mode=plan.framing_mode,
-            applied_matrices=plan.final_matrices),
-        "estimated_motion": plan.estimated_motion,
+            applied_matrices=final_stack),
+        "estimated_motion": {
+            "per_transition": [
+                {"index": i, "mode": mode, "confidence": conf, "residual": resid, "matrix": mat}
+                for i, (mode, conf, resid, mat) in enumerate(zip(em["modes"], em["confidences"], em["residuals"],
+                                                                 np.asarray(em["matrices"], dtype=np.float32).tolist()))
+            ],
+            "path": em["path"].tolist(),
+            "target_path": em["target_path"].tolist(),
+            "target_path_effective": em["target_path_effective"].tolist(),
+        },
         "padding_fraction_mean": None,
         "padding_fraction_max": None,
     }
+    fast = applied_motion_meta_from_arrays(final_stack, plan.source_size, plan.output_size, plan.fps_effective, "estimated_flow")
+    if fast is not None:
+        meta["motion_meta"] = fast
+        return meta
     return _attach_motion_meta(meta, plan.fps_effective)
 
 

@@ -273,6 +273,56 @@ def _params_to_matrix(params: np.ndarray, base_mode: str) -> np.ndarray:
     return np.array([[p[0] + 1.0, p[1], p[2]], [p[3], p[4] + 1.0, p[5]], [p[6], p[7], 1.0]], dtype=np.float32)
 
 
+# element-wise libm calls (exactly what the per-item helpers use) without a Python-level loop
+_ATAN2 = np.frompyfunc(math.atan2, 2, 1)
+_LOG = np.frompyfunc(math.log, 1, 1)
+_SQRT = np.frompyfunc(math.sqrt, 1, 1)
+_EXP = np.frompyfunc(math.exp, 1, 1)
+_COS = np.frompyfunc(math.cos, 1, 1)
+_SIN = np.frompyfunc(math.sin, 1, 1)
+
+
+def matrices_to_params(stack: np.ndarray, base_mode: str) -> np.ndarray:
+    """`_matrix_to_params` for a float32 [N,3,3] stack -> float64 [N,P]; same libm calls, same bits."""
+    m = np.asarray(stack)
+    n = m.shape[0]
+    if base_mode == "translation":
+        return np.stack([m[:, 0, 2], m[:, 1, 2]], axis=1).astype(np.float64)
+    if base_mode == "similarity":
+        a, c = m[:, 0, 0], m[:, 1, 0]
+        sq = a * a + c * c                      # float32 arithmetic, as with the float32 scalars of the per-item form
+        sq64 = np.where(np.float32(1e-10) > sq, 1e-10, sq.astype(np.float64))
+        scale = _SQRT(sq64).astype(np.float64)
+        theta = _ATAN2(c.astype(np.float64), a.astype(np.float64)).astype(np.float64)
+        return np.stack([m[:, 0, 2].astype(np.float64), m[:, 1, 2].astype(np.float64), theta,
+                         _LOG(scale).astype(np.float64)], axis=1) if n else np.zeros((0, 4))
+    m64 = m.astype(np.float64) if m.dtype != np.float64 else m
+    one = np.float32(1.0) if m.dtype == np.float32 else 1.0
+    return np.stack([(m[:, 0, 0] - one).astype(np.float64), m64[:, 0, 1], m64[:, 0, 2], m64[:, 1, 0],
+                     (m[:, 1, 1] - one).astype(np.float64), m64[:, 1, 2], m64[:, 2, 0], m64[:, 2, 1]], axis=1)
+
+
+def params_to_matrices(params: np.ndarray, base_mode: str) -> np.ndarray:
+    """`_params_to_matrix` for float64 [N,P] -> float32 [N,3,3]."""
+    p = np.asarray(params, dtype=np.float64)
+    n = p.shape[0]
+    out = np.zeros((n, 3, 3), np.float64)
+    out[:, 2, 2] = 1.0
+    if base_mode == "translation":
+        out[:, 0, 0] = 1.0; out[:, 1, 1] = 1.0
+        out[:, 0, 2] = p[:, 0]; out[:, 1, 2] = p[:, 1]
+    elif base_mode == "similarity":
+        s = _EXP(p[:, 3]).astype(np.float64)
+        ct, st = _COS(p[:, 2]).astype(np.float64), _SIN(p[:, 2]).astype(np.float64)
+        out[:, 0, 0] = s * ct; out[:, 0, 1] = -s * st; out[:, 0, 2] = p[:, 0]
+        out[:, 1, 0] = s * st; out[:, 1, 1] = s * ct; out[:, 1, 2] = p[:, 1]
+    else:
+        out[:, 0, 0] = p[:, 0] + 1.0; out[:, 0, 1] = p[:, 1]; out[:, 0, 2] = p[:, 2]
+        out[:, 1, 0] = p[:, 3]; out[:, 1, 1] = p[:, 4] + 1.0; out[:, 1, 2] = p[:, 5]
+        out[:, 2, 0] = p[:, 6]; out[:, 2, 1] = p[:, 7]
+    return out.astype(np.float32)
+
+
 def smoothing_window(smooth: float, fps: float) -> int:
     """Odd box-filter length derived from fps (stabilizer_utils.py:367-374)."""
     fps = float(max(1.0, fps))
@@ -369,7 +419,7 @@ def _build_stabilization_warp_meta(*, source_size, output_size, framing_mode, ap
         "framing_mode": framing_mode,
         "matrix_convention": "source_to_stabilized",
         "per_frame": [
-            {"index": int(i), "applied_matrix": np.asarray(m, dtype=np.float32).tolist()}
-            for i, m in enumerate(applied_matrices)
+            {"index": i, "applied_matrix": m}
+            for i, m in enumerate(np.asarray(applied_matrices, dtype=np.float32).reshape(-1, 3, 3).tolist())
         ],
     }

@@ -146,13 +146,44 @@ def build_motion_meta_v2(*, source: str, frame_count: int, fps: float, input_siz
         "output_size": [int(output_size[0]), int(output_size[1])],
         "matrix_convention": INPUT_TO_OUTPUT,
         "per_frame": [
-            {"index": int(pos), "matrix": np.asarray(mat, dtype=np.float64).tolist()} for pos, mat in enumerate(matrices)
+            {"index": pos, "matrix": mat}
+            for pos, mat in enumerate(np.asarray(matrices, dtype=np.float64).reshape(-1, 3, 3).tolist())
         ],
     }
     if generator is not None:
         block["generator"] = dict(generator)
     validate_motion_meta(block)
     return block
+
+
+def applied_motion_meta_from_arrays(applied_f32: np.ndarray, source_size, output_size, fps: float, source: str) -> Dict[str, Any]:
+    """Same block as `applied_motion_meta_from_stabilization_warp(warp_meta, ...)` when warp_meta was itself
+    built from the float32 stack `applied_f32` (hm._build_stabilization_warp_meta): the float32 -> Python
+    float -> float64 round trip is exact, so the checks (finite, invertible) can run on the array once
+    instead of re-parsing N nested lists twice.  Any irregularity defers to the generic path, which raises
+    the reference's exact error."""
+    stack = np.asarray(applied_f32, dtype=np.float32).reshape(-1, 3, 3).astype(np.float64)
+    ok = bool(np.isfinite(stack).all())
+    if ok and stack.shape[0]:
+        try:
+            np.linalg.inv(stack)
+        except np.linalg.LinAlgError:
+            ok = False
+    w0, h0 = int(source_size[0]), int(source_size[1])
+    w1, h1 = int(output_size[0]), int(output_size[1])
+    fps_f = float(fps)
+    if not ok or min(w0, h0, w1, h1) <= 0 or not np.isfinite(fps_f) or fps_f <= 0.0 or not isinstance(source, str) or not source:
+        return None
+    return {
+        "version": 2,
+        "source": source,
+        "frame_count": int(stack.shape[0]),
+        "fps": fps_f,
+        "input_size": [w0, h0],
+        "output_size": [w1, h1],
+        "matrix_convention": INPUT_TO_OUTPUT,
+        "per_frame": [{"index": pos, "matrix": mat} for pos, mat in enumerate(stack.tolist())],
+    }
 
 
 def _warp_block_fields(warp_meta: Any):

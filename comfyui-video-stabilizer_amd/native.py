@@ -41,6 +41,56 @@ class FitRecord(C.Structure):
     ]
 
 
+# numpy view of vstab_fit_record (include/vstab.h): same layout as the ctypes structure above
+FIT_DTYPE = np.dtype({
+    "names": ["matrix", "confidence", "residual", "accepted", "computed", "valid_points", "total_points"],
+    "formats": [(np.float32, (9,)), np.float64, np.float64, np.int32, np.int32, np.int32, np.int32],
+    "offsets": [0, 40, 48, 56, 60, 64, 68],
+    "itemsize": 72,
+})
+assert C.sizeof(FitRecord) == FIT_DTYPE.itemsize
+
+
+def fit_table_from_dicts(records) -> np.ndarray:
+    """List of {mode_name: candidate dict} (the oracle-side shape used in tests) -> structured [P,3] table."""
+    table = np.zeros((len(records), 3), FIT_DTYPE)
+    table["matrix"][:] = np.eye(3, dtype=np.float32).reshape(9)
+    for p, entry in enumerate(records):
+        for mi, name in enumerate(MODE_NAMES):
+            cand = entry.get(name)
+            if cand is None:
+                continue
+            row = table[p, mi]
+            row["matrix"] = np.asarray(cand["matrix"], np.float32).reshape(9)
+            row["confidence"] = cand["confidence"]
+            row["residual"] = cand["residual"]
+            row["accepted"] = 1 if cand["accepted"] else 0
+            row["computed"] = 1
+            row["valid_points"] = cand.get("valid_points", 0)
+            row["total_points"] = cand.get("total_points", 0)
+    return table
+
+
+def fit_table_to_dicts(table: np.ndarray):
+    out = []
+    for p in range(table.shape[0]):
+        entry = {}
+        for mi, name in enumerate(MODE_NAMES):
+            r = table[p, mi]
+            if not r["computed"]:
+                continue
+            entry[name] = {
+                "matrix": np.array(r["matrix"], dtype=np.float32).reshape(3, 3),
+                "confidence": float(r["confidence"]),
+                "residual": float(r["residual"]),
+                "accepted": bool(r["accepted"]),
+                "valid_points": int(r["valid_points"]),
+                "total_points": int(r["total_points"]),
+            }
+        out.append(entry)
+    return out
+
+
 _SIGNATURES = {
     "vstab_abi_version": (C.c_int, []),
     "vstab_last_error": (C.c_char_p, []),
@@ -257,35 +307,19 @@ class Context:
         return flow, grid
 
     def sample_fit_batch(self, grid_flow, step, requested_mode):
-        """grid_flow [P,gh,gw,2] (device) -> list over pairs of {mode_name: FitRecord-like dict}."""
+        """grid_flow [P,gh,gw,2] (device) -> structured table [P,3] (FIT_DTYPE), one row per pair and mode."""
         if grid_flow.device != self.device:
             grid_flow = grid_flow.to(self.device)
         grid_flow = grid_flow.contiguous()
         pairs, gh, gw, _ = grid_flow.shape
-        recs = (FitRecord * (pairs * 3))()
+        table = np.zeros((pairs, 3), FIT_DTYPE)
         self.use_torch_stream()
         _check(
             self.lib.vstab_sample_fit_batch(
-                self.handle, _dev_ptr(grid_flow), pairs, gh, gw, int(step), MODES[requested_mode], C.byref(recs)),
+                self.handle, _dev_ptr(grid_flow), pairs, gh, gw, int(step), MODES[requested_mode], table.ctypes.data),
             "vstab_sample_fit_batch",
         )
-        out = []
-        for p in range(pairs):
-            entry = {}
-            for mi, name in enumerate(MODE_NAMES):
-                r = recs[p * 3 + mi]
-                if not r.computed:
-                    continue
-                entry[name] = {
-                    "matrix": np.array(list(r.matrix), dtype=np.float32).reshape(3, 3),
-                    "confidence": float(r.confidence),
-                    "residual": float(r.residual),
-                    "accepted": bool(r.accepted),
-                    "valid_points": int(r.valid_points),
-                    "total_points": int(r.total_points),
-                }
-            out.append(entry)
-        return out
+        return table
 
     def crop_analysis(self, matrices, src_size, out_size):
         """Nearest coverage of every frame -> (bbox [n,4] of the 3x3-closed coverage or -1, AND of all frames eroded 3x3)."""

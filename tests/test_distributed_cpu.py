@@ -130,9 +130,10 @@ def test_shard_geometry(pkg):
             assert max(sizes) - min(sizes) <= 1
             if total >= world:
                 assert sum(vd.transition_counts(total, world)) == total - 1
+    from vstab_amd import native
+
     recs = fake_records(12)
-    packed = vd.pack_records(recs, 12)
-    back = vd.unpack_records(packed, 11)
+    back = native.fit_table_to_dicts(native.fit_table_from_dicts(recs))
     for a, b in zip(recs, back):
         assert set(a) == set(b)
         for k in a:

@@ -48,7 +48,9 @@ def test_fit_matches_oracle(ctx, oracle, kind, mode):
     h, w, step = 135 * 2, 240 * 2, 8
     flows = np.stack([synth_flow(h, w, kind, seed) for seed in range(4)])
     grid = np.ascontiguousarray(flows[:, ::step, ::step, :])
-    got = ctx.sample_fit_batch(torch.from_numpy(grid).cuda(), step, mode)
+    from vstab_amd import native
+
+    got = native.fit_table_to_dicts(ctx.sample_fit_batch(torch.from_numpy(grid).cuda(), step, mode))
     for p in range(flows.shape[0]):
         ref, nv, nt = oracle.fit_all_modes(flows[p], step, mode)
         assert set(got[p]) == set(ref)
@@ -73,7 +75,9 @@ def test_fit_too_few_valid_points(ctx):
 
     grid = np.full((1, 6, 8, 2), np.nan, np.float32)
     grid[0, 0, :5] = 1.0
-    got = ctx.sample_fit_batch(torch.from_numpy(grid).cuda(), 8, "similarity")
+    from vstab_amd import native
+
+    got = native.fit_table_to_dicts(ctx.sample_fit_batch(torch.from_numpy(grid).cuda(), 8, "similarity"))
     assert got[0] == {}
 
 

@@ -208,3 +208,10 @@ def test_batched_host_math_equals_per_item(hm):
     assert np.array_equal(mins, bmins) and np.array_equal(maxs, bmaxs)
     shift = np.array([[1, 0, 3.25], [0, 1, -7.5], [0, 0, 1]], np.float32)
     assert np.array_equal(np.matmul(shift, stack), np.stack([shift @ m for m in stack]))
+    for mode in ("translation", "similarity", "perspective"):
+        per_item = np.stack([hm._matrix_to_params(m, mode) for m in stack])
+        batch = hm.matrices_to_params(stack, mode)
+        assert batch.dtype == np.float64 and np.array_equal(batch, per_item), mode
+        back_item = np.stack([hm._params_to_matrix(p * 0.37, mode) for p in per_item])
+        back = hm.params_to_matrices(per_item * 0.37, mode)
+        assert back.dtype == np.float32 and np.array_equal(back, back_item), mode
