@@ -9,14 +9,36 @@ from __future__ import annotations
 
 from typing import Any
 
+import os
+
 from . import host_math as hm
 from .apply_pipeline import apply_motion
+from .meta_v2 import resolve_motion_meta
 from .comfy_compat import ComfyExtension, ProgressBar, io
 from .flow_pipeline import _stabilize_frames
 
 JSONType = io.Custom("JSON")
 
 BLUR_QUALITY_SAMPLES = {"Draft": 5, "Standard": 9, "High": 17, "Ultra": 33}  # motion_apply node :21-26
+
+
+def _keep_on_device() -> bool:
+    """with VSTAB_KEEP_ON_DEVICE=1 the IMAGE / MASK outputs stay in HBM (torch device tensors), so a
+    Flow -> Motion Apply chain avoids the 15 GB host round trip of a 256x1080p clip.  Default: CPU tensors, as
+    the reference returns (stabilizer_utils.py:200-221)."""
+    return os.environ.get("VSTAB_KEEP_ON_DEVICE", "0") not in ("", "0", "false", "False")
+
+
+def _image_out(frames, context):
+    if _keep_on_device() and hasattr(frames, "device") and context.template_kind != "dict":
+        return frames
+    return hm._reconstruct_video(frames, context)
+
+
+def _mask_out(masks):
+    if _keep_on_device() and hasattr(masks, "device"):
+        return masks[..., 0] if masks.ndim == 4 else masks
+    return hm._convert_masks_for_output(masks)
 
 
 class VideoStabilizerFlow(io.ComfyNode):
@@ -74,8 +96,7 @@ class VideoStabilizerFlow(io.ComfyNode):
             context, framing_mode, transform_mode, camera_lock, strength, smooth, keep_fov,
             hm._parse_padding_color(padding_color), frame_rate, keep_on_device=True,
         )
-        return io.NodeOutput(hm._reconstruct_video(result.frames, context),
-                             hm._convert_masks_for_output(result.masks), result.meta)
+        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
 
 
 class VideoStabilizerMotionApply(io.ComfyNode):
@@ -134,13 +155,87 @@ class VideoStabilizerMotionApply(io.ComfyNode):
                               motion_blur_samples=samples, progress_callback=tick, keep_on_device=True)
         result.meta.setdefault("motion_apply", {})["motion_blur_quality"] = quality
         pbar.update_absolute(total, total)
-        return io.NodeOutput(hm._reconstruct_video(result.frames, context),
-                             hm._convert_masks_for_output(result.masks), result.meta)
+        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
 
 
-NODE_CLASSES = [VideoStabilizerFlow, VideoStabilizerMotionApply]
+class VideoStabilizerInverse(io.ComfyNode):
+    """Deprecated thin wrapper kept for graph compatibility (nodes/video_stabilizer_inverse.py:26-93 of the
+    reference): inverse of the recorded stabilization warp through Motion Apply (crop_and_pad, bilinear)."""
+
+    @classmethod
+    def define_schema(cls) -> io.Schema:
+        schema = io.Schema(
+            node_id="video_stabilizer_inverse",
+            display_name="Video Stabilizer Inverse",
+            category="Video/Stabilization",
+            description=("Deprecated: use Video Stabilizer Motion Apply. Restores stabilized frames to the original "
+                         "canvas using stabilization metadata, and emits a padding mask for areas without source pixels."),
+            is_deprecated=True,
+        )
+        schema.inputs = [
+            io.Image.Input("frames", display_name="Frames"),
+            JSONType.Input("meta", display_name="Meta"),
+            io.Color.Input("padding_color", default="#7F7F7F", display_name="Padding Color",
+                           tooltip="HEX padding color used where inverse warping exposes empty pixels."),
+        ]
+        schema.outputs = [
+            io.Image.Output("frames_restored", display_name="Restored Frames"),
+            io.Mask.Output("padding_mask", display_name="Padding Mask"),
+            JSONType.Output("meta", display_name="Meta"),
+        ]
+        return schema
+
+    @classmethod
+    def execute(cls, frames: Any, meta: dict, padding_color: str) -> io.NodeOutput:
+        context = hm._normalize_video_input(frames)
+        legacy = dict(meta)
+        legacy.pop("motion_meta", None)   # force the inverse of stabilization_warp
+        motion = resolve_motion_meta(legacy)
+        result = apply_motion(context, legacy, hm._parse_padding_color(padding_color), framing_mode="crop_and_pad",
+                              interpolation="bilinear", keep_on_device=True)
+        if isinstance(meta, dict) and isinstance(meta.get("motion_meta"), dict):
+            result.meta["motion_meta"] = meta["motion_meta"]
+        result.meta.pop("motion_apply", None)
+        warp = meta.get("stabilization_warp", {}) if isinstance(meta, dict) else {}
+        result.meta["inverse_stabilization"] = {
+            "source_size": [int(motion.output_size[0]), int(motion.output_size[1])],
+            "input_size": [int(motion.input_size[0]), int(motion.input_size[1])],
+            "output_size": [int(motion.output_size[0]), int(motion.output_size[1])],
+            "matrix_convention": "stabilized_to_source",
+            "source_matrix_convention": "source_to_stabilized",
+            "framing_mode": warp.get("framing_mode") if isinstance(warp, dict) else None,
+            "note": "Restores original motion/canvas; pixels discarded by crop framing cannot be recovered.",
+        }
+        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
+
+
+NODE_CLASSES = [VideoStabilizerFlow, VideoStabilizerMotionApply, VideoStabilizerInverse]
 
 
 class VideoStabilizerAmdExtension(ComfyExtension):
     async def get_node_list(self) -> list:
         return list(NODE_CLASSES)
+
+    async def on_load(self) -> None:
+        """Graph migration Inverse -> Motion Apply, as nodes/node_replacements.py:8-27 registers it (only inside
+        a ComfyUI that exposes the node-replacement API)."""
+        try:
+            from comfy_api.latest import ComfyAPI  # type: ignore
+        except ImportError:
+            return
+        api = ComfyAPI()
+        await api.node_replacement.register(
+            io.NodeReplace(
+                new_node_id="video_stabilizer_motion_apply",
+                old_node_id="video_stabilizer_inverse",
+                old_widget_ids=["padding_color"],
+                input_mapping=[
+                    {"new_id": "frames", "old_id": "frames"},
+                    {"new_id": "motion_meta", "old_id": "meta"},
+                    {"new_id": "padding_color", "old_id": "padding_color"},
+                    {"new_id": "framing_mode", "set_value": "crop_and_pad"},
+                    {"new_id": "interpolation", "set_value": "bilinear"},
+                ],
+                output_mapping=[{"new_idx": 0, "old_idx": 0}, {"new_idx": 1, "old_idx": 1}, {"new_idx": 2, "old_idx": 2}],
+            )
+        )

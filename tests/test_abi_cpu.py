@@ -70,6 +70,10 @@ def test_node_schema_sockets(pkg):
                                         "motion_blur", "motion_blur_quality"]
     assert [o.id for o in s.outputs] == ["frames", "padding_mask", "meta"]
     assert nodes.BLUR_QUALITY_SAMPLES == {"Draft": 5, "Standard": 9, "High": 17, "Ultra": 33}
+    s = nodes.VideoStabilizerInverse.define_schema()
+    assert s.node_id == "video_stabilizer_inverse" and s.is_deprecated
+    assert [i.id for i in s.inputs] == ["frames", "meta", "padding_color"]
+    assert [o.id for o in s.outputs] == ["frames_restored", "padding_mask", "meta"]
 
 
 # ---------------------------------------------------------------- oracle known answers (no GPU)

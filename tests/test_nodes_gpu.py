@@ -226,3 +226,35 @@ def test_flow_node_small_paths(api, ctx):
     assert out[2]["smooth"] == 0.85 and np.all(np.array(out[2]["estimated_motion"]["target_path"]) == 0.0)
     out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "crop", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
     assert out[2]["framing"]["mode"] == "crop" and float(out[1].max()) == 0.0
+
+
+def test_expand_then_inverse_round_trip(api, ctx):
+    """KA9 (check_inverse_stabilization.py:161-165): expand -> inverse restores the clip, p99 <= 0.3, mean <= 0.035;
+    also the device-resident chaining switch (N3)."""
+    import os
+
+    import torch
+
+    from tests.test_dis_gpu import moving_clip
+
+    gray, _ = moving_clip(6, 270, 480, seed=21)
+    frames = np.ascontiguousarray(np.repeat(gray[..., None].astype(np.float32) / 255.0, 3, axis=-1))
+    out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "expand", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    stab, meta = out[0], out[2]
+    inv = api.nodes.VideoStabilizerInverse.execute(stab, meta, "#7F7F7F")
+    restored, mask, imeta = inv[0].numpy(), inv[1].numpy(), inv[2]
+    assert restored.shape == frames.shape and restored.dtype == np.float32 and mask.shape == frames.shape[:3]
+    valid = mask < 0.5
+    err = np.abs(restored - frames)[valid]
+    assert np.percentile(err, 99) <= 0.3 and err.mean() <= 0.035
+    assert imeta["inverse_stabilization"]["output_size"] == [480, 270] and "motion_apply" not in imeta
+    assert imeta["motion_meta"] == meta["motion_meta"]
+    os.environ["VSTAB_KEEP_ON_DEVICE"] = "1"
+    try:
+        out = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), 16.0, "expand", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+        assert out[0].is_cuda and out[1].is_cuda and out[1].ndim == 3
+        chained = api.nodes.VideoStabilizerMotionApply.execute(out[0], {"stabilization_warp": meta["stabilization_warp"]}, "crop_and_pad",
+                                                               "bilinear", "#7F7F7F", 0.0, "Standard")
+        assert chained[0].is_cuda and np.array_equal(chained[0].cpu().numpy(), restored)
+    finally:
+        del os.environ["VSTAB_KEEP_ON_DEVICE"]
