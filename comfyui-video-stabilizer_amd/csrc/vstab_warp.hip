@@ -386,8 +386,8 @@ void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t s
 template <bool BLUR>
 int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t st)
 {
-    const int tx = getenv("VSTAB_WARP_TX") ? atoi(getenv("VSTAB_WARP_TX")) : 32;
-    a.nt_store = getenv("VSTAB_WARP_NT") ? atoi(getenv("VSTAB_WARP_NT")) : 0;
+    const int tx = 32;   // 128 x 8 tile: best of {8,16,32,64} threads along x (profiles/r01_warp_tile_sweep.md)
+    a.nt_store = 0;      // nontemporal stores measured neutral
     a.tiles_x = (a.dw + tx * TILE_PX - 1) / (tx * TILE_PX);
     a.tiles_y = (a.dh + 256 / tx - 1) / (256 / tx);
     const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
