@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int FIT_THREADS = 256;
-constexpr int RANSAC_BATCH = 32;
+constexpr int RANSAC_BATCH = 16;   // typical clips converge in < 10 iterations; 16 keeps the scoring loop in registers
 constexpr int MAX_SORT = 16384;
 
 struct Rng { unsigned long long state; };

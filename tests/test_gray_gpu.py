@@ -39,3 +39,18 @@ def test_gray_1080p_properties(ctx):
     frames4k = torch.full((1, 2160, 3840, 3), 1.0, dtype=torch.float32)
     g = ctx.gray_downscale(frames4k, (960, 540)).cpu().numpy()
     assert np.all(g == 255) or np.all(g == 254)
+
+
+def test_4k_sizes(ctx, oracle):
+    """BASELINE configs[4] frame size (3840x2160): 4x4 area path vs the oracle on two frames, and an
+    identity warp at 4K (size-independent property)."""
+    import torch
+
+    g = torch.Generator().manual_seed(4)
+    frames = torch.rand((2, 2160, 3840, 3), generator=g, dtype=torch.float32)
+    got = ctx.gray_downscale(frames, (960, 540)).cpu().numpy()
+    ref = oracle.gray_for_estimation(frames.numpy(), (960, 540))
+    assert np.array_equal(got, ref)
+    eye = np.tile(np.eye(3, dtype=np.float32), (2, 1, 1))
+    dst, mask, cnt = ctx.warp_batch(frames, eye, (3840, 2160), border=(0.5, 0.5, 0.5), want_count=True)
+    assert torch.equal(dst.cpu(), frames) and int(cnt.sum()) == 0
