@@ -166,37 +166,35 @@ __global__ __launch_bounds__(256) void sobel_kernel(const uint8_t* __restrict__ 
     }
 }
 
-// precomputeStructureTensor, horizontal running sums: one thread per (quantity, frame, row); each running
-// sum is sequential along the row exactly as OpenCV accumulates it (f32), the five quantities are independent
+// precomputeStructureTensor, horizontal running sums: one thread per (frame,row)
 __global__ __launch_bounds__(64) void tensor_h_kernel(const short* __restrict__ Ix, const short* __restrict__ Iy, float* __restrict__ aux,
                                                       int n, int h, int w, int ws)
 {
     const long long rows = (long long)n * h;
     const size_t plane = (size_t)n * h * ws;
-    GRID_STRIDE(t5, rows * 5) {
-        const int k = (int)(t5 / rows);            // 0: xx, 1: yy, 2: xy, 3: x, 4: y
-        const long long t = t5 - (long long)k * rows;
+    GRID_STRIDE(t, rows) {
         const short* xr = Ix + (size_t)t * w;
         const short* yr = Iy + (size_t)t * w;
-        const short* A = (k == 1 || k == 4) ? yr : xr;
-        const short* B = (k == 0) ? xr : yr;       // second factor of the products (unused for k >= 3)
-        float* o = aux + (size_t)k * plane + (size_t)t * ws;
-        float s = 0.f;
-        if (k < 3) {
-            for (int j = 0; j < PSZ; j++) s += A[j] * B[j];
-            o[0] = s;
-            int js = 1;
-            for (int j = PSZ; j < w; j++) {
-                s += (A[j] * B[j] - A[j - PSZ] * B[j - PSZ]);
-                if ((j - PSZ + 1) % PSTR == 0) o[js++] = s;
-            }
-        } else {
-            for (int j = 0; j < PSZ; j++) s += A[j];
-            o[0] = s;
-            int js = 1;
-            for (int j = PSZ; j < w; j++) {
-                s += (A[j] - A[j - PSZ]);
-                if ((j - PSZ + 1) % PSTR == 0) o[js++] = s;
+        float* o = aux + (size_t)t * ws;
+        float s_xx = 0.f, s_yy = 0.f, s_xy = 0.f, s_x = 0.f, s_y = 0.f;
+        for (int j = 0; j < PSZ; j++) {
+            s_xx += xr[j] * xr[j];
+            s_yy += yr[j] * yr[j];
+            s_xy += xr[j] * yr[j];
+            s_x += xr[j];
+            s_y += yr[j];
+        }
+        o[0] = s_xx; o[plane] = s_yy; o[2 * plane] = s_xy; o[3 * plane] = s_x; o[4 * plane] = s_y;
+        int js = 1;
+        for (int j = PSZ; j < w; j++) {
+            s_xx += (xr[j] * xr[j] - xr[j - PSZ] * xr[j - PSZ]);
+            s_yy += (yr[j] * yr[j] - yr[j - PSZ] * yr[j - PSZ]);
+            s_xy += (xr[j] * yr[j] - xr[j - PSZ] * yr[j - PSZ]);
+            s_x += (xr[j] - xr[j - PSZ]);
+            s_y += (yr[j] - yr[j - PSZ]);
+            if ((j - PSZ + 1) % PSTR == 0) {
+                o[js] = s_xx; o[plane + js] = s_yy; o[2 * plane + js] = s_xy; o[3 * plane + js] = s_x; o[4 * plane + js] = s_y;
+                js++;
             }
         }
     }
@@ -970,7 +968,7 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
         const long long px = (long long)n * g.h * g.w;
         hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)n * (g.h + 32) * (g.w + 32))), dim3(256), 0, st, I[i], Iext[i], n, g.h, g.w);
         hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(px)), dim3(256), 0, st, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for(5LL * n * g.h, 64)), dim3(64), 0, st, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h, 64)), dim3(64), 0, st, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
         hipLaunchKernelGGL(tensor_v_kernel, dim3(grid_for(5LL * n * g.ws, 64)), dim3(64), 0, st, aux, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
     }
