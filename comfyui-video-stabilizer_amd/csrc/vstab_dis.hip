@@ -29,7 +29,7 @@ constexpr float DIS_INF = 1e10f;
 constexpr int DIS_BORDER = 16;
 constexpr int PSZ = 8;
 constexpr int PSTR = 4;
-constexpr int FINEST = 2;
+constexpr int DEFAULT_FINEST = 2;   // flow.py:83 setFinestScale(2)
 constexpr int GD_ITERS = 25;
 constexpr int VAR_ITERS = 5;
 constexpr int SOR_ITERS = 5;
@@ -892,24 +892,24 @@ int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh,
 
 }  // namespace
 
-extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, float* flow, float* grid_flow,
-                                    int sample_step)
+// DISOpticalFlowImpl::calc scale selection incl. autoSelectPatchSizeAndScales (finest 2 -> default branch)
+static bool dis_scales(int h, int w, int& finest, int& coarsest)
 {
-    VSTAB_REQUIRE(ctx != nullptr, "vstab_dis_flow_batch: ctx is NULL");
-    VSTAB_REQUIRE(gray != nullptr, "vstab_dis_flow_batch: gray is NULL");
-    VSTAB_REQUIRE(n >= 2, "vstab_dis_flow_batch: need at least 2 frames, got %d", n);
-    VSTAB_REQUIRE(flow != nullptr || grid_flow != nullptr, "vstab_dis_flow_batch: no output requested");
-    VSTAB_REQUIRE(sample_step >= 1, "vstab_dis_flow_batch: sample_step must be >= 1");
-    VSTAB_REQUIRE(h > 0 && w > 0, "vstab_dis_flow_batch: non-positive size");
-    const int coarsest = coarsest_scale(h, w);
-    // OpenCV would re-select patch size / scales for tiny images (autoSelectPatchSizeAndScales); that
-    // path is not implemented: fail loudly instead of silently differing.
-    VSTAB_REQUIRE(coarsest >= FINEST && coarsest < MAX_LEVELS,
-                  "vstab_dis_flow_batch: %dx%d is too small for finest scale %d (coarsest %d)", w, h, FINEST, coarsest);
-    VSTAB_HIP(hipSetDevice(ctx->device));
+    coarsest = coarsest_scale(h, w);
+    if (coarsest < 0) return false;
+    if (coarsest < finest) {
+        const int c = (int)std::floor(std::log2((2.0f * (float)w) / (5.0f * (float)PSZ)));
+        coarsest = c > 0 ? c : 0;
+        finest = coarsest - 2 > 0 ? coarsest - 2 : 0;
+    }
+    return coarsest < MAX_LEVELS;
+}
+
+static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int FINEST, int coarsest, float* flow, float* grid_flow,
+                   int sample_step)
+{
     hipStream_t st = ctx->stream;
     const int P = n - 1;
-
     LevelGeom G[MAX_LEVELS];
     {
         int fraction = 1, ch = 0, cw = 0;
@@ -957,8 +957,6 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
     }
     Carver carver(ctx->d_dis.ptr);
     layout(carver);
-
-    KernelTimer timer(ctx, "dis");
 
     // ---- per-frame preparation: pyramid, padded copies, gradients, structure tensor ----
     for (int i = FINEST; i <= coarsest; i++) {
@@ -1039,5 +1037,38 @@ extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, 
                            h, w, 1, fsx, fsy, mul);
     }
     VSTAB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, float* flow, float* grid_flow,
+                                    int sample_step)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_dis_flow_batch: ctx is NULL");
+    VSTAB_REQUIRE(gray != nullptr, "vstab_dis_flow_batch: gray is NULL");
+    VSTAB_REQUIRE(n >= 2, "vstab_dis_flow_batch: need at least 2 frames, got %d", n);
+    VSTAB_REQUIRE(flow != nullptr || grid_flow != nullptr, "vstab_dis_flow_batch: no output requested");
+    VSTAB_REQUIRE(sample_step >= 1, "vstab_dis_flow_batch: sample_step must be >= 1");
+    VSTAB_REQUIRE(h > 0 && w > 0, "vstab_dis_flow_batch: non-positive size");
+    // One DIS object serves the whole clip in the reference (flow.py:316): its first calc() may auto-select the
+    // scales for a tiny image and keeps the new finest scale; later calls recompute the coarsest scale only.
+    int f0 = DEFAULT_FINEST, c0 = 0;
+    VSTAB_REQUIRE(dis_scales(h, w, f0, c0), "vstab_dis_flow_batch: %dx%d is too small for DIS (OpenCV needs width or height >= 12)", w, h);
+    int f1 = f0, c1 = 0;
+    VSTAB_REQUIRE(dis_scales(h, w, f1, c1), "vstab_dis_flow_batch: scale selection failed for %dx%d", w, h);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    KernelTimer timer(ctx, "dis");
+    const bool stateful = ctx->dis_first_pair_is_clip_start && (c1 != c0 || f1 != f0);
+    if (!stateful) return dis_run(ctx, gray, n, h, w, ctx->dis_first_pair_is_clip_start ? f0 : f1, ctx->dis_first_pair_is_clip_start ? c0 : c1, flow, grid_flow, sample_step);
+    if (int rc = dis_run(ctx, gray, 2, h, w, f0, c0, flow, grid_flow, sample_step)) return rc;
+    if (n == 2) return 0;
+    const int gh = (h + sample_step - 1) / sample_step, gw = (w + sample_step - 1) / sample_step;
+    return dis_run(ctx, gray + (size_t)h * w, n - 1, h, w, f1, c1, flow ? flow + (size_t)h * w * 2 : nullptr,
+                   grid_flow ? grid_flow + (size_t)gh * gw * 2 : nullptr, sample_step);
+}
+
+extern "C" int vstab_dis_set_clip_start(vstab_ctx* ctx, int first_pair_is_clip_start)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_dis_set_clip_start: ctx is NULL");
+    ctx->dis_first_pair_is_clip_start = first_pair_is_clip_start != 0;
     return 0;
 }

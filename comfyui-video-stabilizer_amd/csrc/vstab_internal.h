@@ -44,6 +44,7 @@ struct vstab_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    bool dis_first_pair_is_clip_start = true;   // see vstab_dis_set_clip_start
     std::map<std::string, EventPair> timers;
     // staging for small per-call parameter tables (pinned host + device mirror)
     ScratchBuf h_params, d_params;

@@ -111,7 +111,7 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     working_size = hm._working_estimation_size(width, height)
     from . import native
 
-    local_records = (estimate_transitions(ctx, local_frames, working_size, transform_mode) if local_frames.shape[0] >= 2
+    local_records = (estimate_transitions(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
                      else np.zeros((0, 3), native.FIT_DTYPE))
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)
     plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,

@@ -111,10 +111,10 @@ def select_transitions(fit_records, requested_mode: str):
     return mats, modes, confs.tolist(), resids.tolist(), _MODE_NAME[active]
 
 
-def estimate_transitions(ctx, device_frames, working_size, transform_mode: str):
-    """F2-F5 for frames [N,H,W,3] on the device -> per-pair candidate fits (list of dicts)."""
+def estimate_transitions(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
+    """F2-F5 for frames [N,H,W,3] on the device -> per-pair candidate fits (structured table [N-1,3])."""
     gray = ctx.gray_downscale(device_frames, working_size)
-    _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True)
+    _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True, clip_start=clip_start)
     return ctx.sample_fit_batch(grid, SAMPLE_STEP, transform_mode)
 
 

@@ -114,6 +114,7 @@ _SIGNATURES = {
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_dis_flow_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vstab_dis_set_clip_start": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_sample_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_crop_analysis": (
@@ -283,9 +284,11 @@ class Context:
                "vstab_gray_downscale")
         return gray
 
-    def dis_flow_batch(self, gray, sample_step=8, want_full=False, want_grid=True):
-        """gray u8 [N,h,w] (device) -> (flow [N-1,h,w,2] | None, grid_flow [N-1,gh,gw,2] | None)."""
+    def dis_flow_batch(self, gray, sample_step=8, want_full=False, want_grid=True, clip_start=True):
+        """gray u8 [N,h,w] (device) -> (flow [N-1,h,w,2] | None, grid_flow [N-1,gh,gw,2] | None).
+        clip_start=False: these frames are a later shard of a clip (see vstab_dis_set_clip_start)."""
         torch = self.torch
+        _check(self.lib.vstab_dis_set_clip_start(self.handle, 1 if clip_start else 0), "vstab_dis_set_clip_start")
         if gray.device != self.device:
             gray = gray.to(self.device)
         gray = gray.contiguous()

@@ -114,6 +114,12 @@ int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, 
 int vstab_dis_flow_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w,
                          float* flow, float* grid_flow, int sample_step);
 
+/* OpenCV's DIS object is stateful for tiny images: its first calc() may auto-select patch size / scales
+ * (autoSelectPatchSizeAndScales) and keeps the new finest scale for the following calls.  The reference
+ * creates one object per clip (flow.py:316), so the first pair of a CLIP can use a different pyramid than
+ * the rest.  A rank that processes a later shard of the clip clears this flag (default: 1). */
+int vstab_dis_set_clip_start(vstab_ctx* ctx, int first_pair_is_clip_start);
+
 /* ---- F4 + F5: model fit on the sampled flow -------------------------------
  * Replaces nodes/video_stabilizer_flow.py:141-210 for every pair: RANSAC
  * homography (cv2.findHomography 2.5 px / 2000 / 0.992, accept >= 0.15),

@@ -609,18 +609,29 @@ static int dis_pair(const Level* L0, const Level* L1, int h, int w, const vo_dis
     return 0;
 }
 
-static int dis_check(int h, int w, const vo_dis_params* p, int* coarsest)
+/* DISOpticalFlowImpl::calc: coarsest scale from the image size; if it is below the finest scale,
+ * autoSelectPatchSizeAndScales() (finest_scale 2 -> "default" branch): patch 8,
+ * coarsest = max(0, floor(log2(2*w / (5*8)))), finest = max(coarsest - 2, 0).  The DIS object keeps the
+ * modified finest_scale for later calls (the reference reuses one object for the whole clip). */
+static int dis_scales(int h, int w, vo_dis_params* p, int* coarsest)
 {
     if (p->patch_size != 8 || !p->use_mean_norm || !p->use_spatial_prop) return -1;
     *coarsest = vo_dis_coarsest_scale(h, w, p->patch_size);
-    if (*coarsest < p->finest_scale || *coarsest >= MAX_LEVELS) return -2; /* autoSelect path not restated */
+    if (*coarsest < 0) return -3; /* OpenCV: "The input image must have either width or height >= 12" */
+    if (*coarsest < p->finest_scale) {
+        int c = (int)floor(log2((2.0f * (float)w) / (5.0f * (float)p->patch_size)));
+        *coarsest = c > 0 ? c : 0;
+        p->finest_scale = *coarsest - 2 > 0 ? *coarsest - 2 : 0;
+    }
+    if (*coarsest >= MAX_LEVELS) return -2;
     return 0;
 }
 
-int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis_params* p, float* flow)
+int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis_params* p_in, float* flow)
 {
     int coarsest;
-    int rc = dis_check(h, w, p, &coarsest);
+    vo_dis_params pl = *p_in, *p = &pl;
+    int rc = dis_scales(h, w, p, &coarsest);
     if (rc) return rc;
     Level L0[MAX_LEVELS], L1[MAX_LEVELS];
     memset(L0, 0, sizeof(L0));
@@ -632,11 +643,8 @@ int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis
     return rc;
 }
 
-int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, float* flow)
+static int dis_clip_range(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, int coarsest, float* flow)
 {
-    int coarsest;
-    int rc = dis_check(h, w, p, &coarsest);
-    if (rc) return rc;
     Level* all = (Level*)calloc((size_t)n * MAX_LEVELS, sizeof(Level));
 #pragma omp parallel for schedule(dynamic)
     for (int f = 0; f < n; f++)
@@ -648,4 +656,22 @@ int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_para
     for (size_t i = 0; i < (size_t)n * MAX_LEVELS; i++) level_free(&all[i]);
     free(all);
     return 0;
+}
+
+/* one DIS object for the whole clip (flow.py:316): the first calc() may auto-select scales and keeps the
+ * new finest scale; later calls recompute the coarsest scale from the image size */
+int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p_in, float* flow)
+{
+    vo_dis_params p0 = *p_in, p1;
+    int c0, c1;
+    int rc = dis_scales(h, w, &p0, &c0);
+    if (rc) return rc;
+    p1 = p0;
+    rc = dis_scales(h, w, &p1, &c1);
+    if (rc) return rc;
+    if (n < 2) return 0;
+    if (c1 == c0 && p1.finest_scale == p0.finest_scale) return dis_clip_range(gray, n, h, w, &p0, c0, flow);
+    rc = dis_clip_range(gray, 2, h, w, &p0, c0, flow);
+    if (rc || n == 2) return rc;
+    return dis_clip_range(gray + (size_t)h * w, n - 1, h, w, &p1, c1, flow + (size_t)h * w * 2);
 }

@@ -43,7 +43,10 @@ def moving_clip(n, h, w, seed=0):
     return np.stack(frames), params
 
 
-@pytest.mark.parametrize("n,h,w", [(3, 135, 240), (3, 270, 480), (2, 120, 213), (2, 100, 160)])
+@pytest.mark.parametrize("n,h,w", [(3, 135, 240), (3, 270, 480), (2, 120, 213), (2, 100, 160),
+                                   (4, 45, 73),    # tiny: OpenCV auto-selects finest 0 / coarsest 1
+                                   (4, 40, 40),    # tiny + stateful: the first pair uses another pyramid than the rest
+                                   (2, 64, 96)])
 def test_dis_matches_oracle(ctx, oracle, n, h, w):
     import torch
 

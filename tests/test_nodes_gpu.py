@@ -258,3 +258,33 @@ def test_expand_then_inverse_round_trip(api, ctx):
         assert chained[0].is_cuda and np.array_equal(chained[0].cpu().numpy(), restored)
     finally:
         del os.environ["VSTAB_KEEP_ON_DEVICE"]
+
+
+@pytest.mark.parametrize("framing,mode,keep_fov", [("crop_and_pad", "similarity", 0.6), ("expand", "translation", 0.6),
+                                                   ("crop", "translation", 1.0)])
+def test_reference_script_scenarios_on_tiny_clip(api, ctx, oracle, framing, mode, keep_fov):
+    """The three Flow scenarios of scripts/compare_refactor_behavior.py:380-393 on an 8-frame 73x45 clip at 24 fps
+    (DIS auto-selects its scales at this size); every stage is checked against the oracle."""
+    yy, xx = np.mgrid[0:45, 0:73].astype(np.float32)
+    frames = np.zeros((8, 45, 73, 3), np.float32)
+    for i in range(8):
+        sx, sy = xx - 0.7 * i, yy - 0.35 * i
+        frames[i, ..., 0] = 0.5 + 0.4 * np.sin(sx * 0.31) * np.cos(sy * 0.23)
+        frames[i, ..., 1] = 0.5 + 0.4 * np.cos(sx * 0.17 + sy * 0.29)
+        frames[i, ..., 2] = ((np.floor(sx / 5) + np.floor(sy / 7)) % 2) * 0.8 + 0.1
+    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), framing, mode, False, 0.7, 0.5, keep_fov, (127, 127, 127), 24.0)
+    if framing == "crop":
+        assert np.array_equal(res.frames, frames) and res.meta["note"].startswith("keep_fov~=1.0") and res.masks.max() == 0.0
+        return
+    g = oracle.gray_for_estimation(frames, None)
+    flow = oracle.dis_flow_clip(g)
+    recs = [oracle.fit_all_modes(flow[i], 8, mode)[0] for i in range(7)]
+    mats, modes, confs, resids, active = api.fp.select_transitions(recs, mode)
+    for i, t in enumerate(res.meta["estimated_motion"]["per_transition"]):
+        assert t["mode"] == modes[i] and t["confidence"] == confs[i]
+        assert np.allclose(np.array(t["matrix"], np.float32), mats[i], rtol=0, atol=1e-6)
+    fm = np.array([e["applied_matrix"] for e in res.meta["stabilization_warp"]["per_frame"]], np.float32)
+    out_size = tuple(res.meta["stabilization_warp"]["output_size"])
+    ref, ref_mask, _ = oracle.warp_clip(frames, fm, out_size, border=BORDER)
+    assert np.array_equal(res.frames, ref) and np.array_equal(res.masks[..., 0], ref_mask)
+    assert res.meta["fps_effective"] == 24.0
