@@ -215,3 +215,18 @@ def test_batched_host_math_equals_per_item(hm):
         back_item = np.stack([hm._params_to_matrix(p * 0.37, mode) for p in per_item])
         back = hm.params_to_matrices(per_item * 0.37, mode)
         assert back.dtype == np.float32 and np.array_equal(back, back_item), mode
+
+
+def test_input_errors_and_soft_paths(hm):
+    """Mixed layouts raise (stabilizer_utils.py:179-180); >3 channels are truncated, gray is repeated."""
+    import torch
+
+    a = np.zeros((6, 8, 3), np.float32)
+    with pytest.raises(ValueError, match="Mixed tensor layouts within the same video sequence are not supported."):
+        hm._normalize_video_input([a, torch.zeros((6, 8, 3))])
+    with pytest.raises(ValueError, match="Mixed tensor layouts"):
+        hm._normalize_video_input([a, np.zeros((3, 6, 8), np.float32)])
+    c = hm._normalize_video_input([np.zeros((6, 8, 5), np.float32)])
+    assert c.frames[0].shape == (6, 8, 3) and c.channels == 3
+    c = hm._normalize_video_input([np.ones((6, 8), np.float32)])
+    assert c.frames[0].shape == (6, 8, 3) and c.channels == 3

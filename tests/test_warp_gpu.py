@@ -113,3 +113,41 @@ def test_full_size_properties(ctx):
     assert float(m[:, h - 3 :, :].min()) == 1.0 and float(m[:, :, :5].min()) == 1.0
     expect = h * w - (h - 3) * (w - 5)
     assert cnt.cpu().tolist() == [expect] * n
+
+
+def test_c_abi_error_reporting(ctx):
+    """Failures cross the ABI as a status + vstab_last_error(), surfaced as VstabError with the message."""
+    import torch
+
+    from vstab_amd import native
+
+    frames = torch.zeros((1, 8, 8, 3))
+    with pytest.raises(native.VstabError, match="unknown interpolation|interp"):
+        ctx.lib.vstab_warp_batch.argtypes  # noqa: B018 - signature is set
+        native._check(ctx.lib.vstab_warp_batch(ctx.handle, frames.cuda().data_ptr(), 1, 8, 8, np.eye(3, dtype=np.float32).ctypes.data,
+                                               8, 8, 7, BORDER.ctypes.data, 0, frames.cuda().data_ptr(), None, None), "vstab_warp_batch")
+    with pytest.raises(native.VstabError, match="exact sub-pixel mode exists for bilinear only"):
+        ctx.warp_batch(frames, np.eye(3, dtype=np.float32)[None], (8, 8), interp="bicubic", subpix="exact")
+    with pytest.raises(native.VstabError, match="samples=40"):
+        native._check(ctx.lib.vstab_warp_blur_batch(ctx.handle, frames.cuda().data_ptr(), 1, 8, 8, np.eye(3).ctypes.data,
+                                                    np.zeros(40).ctypes.data, 40, 8, 8, 0, BORDER.ctypes.data, 0,
+                                                    frames.cuda().data_ptr(), None), "vstab_warp_blur_batch")
+    with pytest.raises(native.VstabError, match="at least 2 frames|at least two"):
+        ctx.dis_flow_batch(torch.zeros((1, 64, 64), dtype=torch.uint8).cuda())
+    with pytest.raises(native.VstabError, match="too small for DIS"):
+        ctx.dis_flow_batch(torch.zeros((2, 6, 6), dtype=torch.uint8).cuda())
+
+
+def test_odd_output_sizes_and_single_pixel_frames(ctx, oracle):
+    """Ragged shapes: 1-pixel-wide / 1-row sources, outputs not divisible by 4, output larger than source."""
+    rng = np.random.default_rng(0)
+    for (sh, sw, dh, dw) in [(1, 9, 3, 11), (7, 1, 9, 5), (5, 5, 17, 19), (33, 65, 31, 63)]:
+        frames = rng.random((2, sh, sw, 3), dtype=np.float32)
+        mats = np.tile(np.eye(3, dtype=np.float32), (2, 1, 1))
+        mats[:, 0, 2] = [0.4, -1.3]
+        mats[:, 1, 2] = [1.6, 0.2]
+        for interp in ("bilinear", "bicubic"):
+            ref, ref_mask, ref_cnt = oracle.warp_clip(frames, mats, (dw, dh), interp=interp, border=BORDER)
+            dst, mask, cnt = ctx.warp_batch(frames, mats, (dw, dh), interp=interp, border=BORDER, want_count=True)
+            assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
+            assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
