@@ -59,10 +59,19 @@ struct FitArgs {
     int* vmap;                // [pairs][gh*gw] compacted index -> grid index
     vstab_fit_record* out;    // [pairs*3]
     int pairs, gh, gw, step, requested_mode;
+    const int* counts;        // point-pair mode (gw == 0): detected features per pair, rows of `cap` entries
+    int cap;
 };
 
+// gw > 0: stride-`step` grid over a flow field (F = [gh][gw][2] displacements, flow.py:141-147);
+// gw == 0: explicit point pairs (F = [cap][4]: prev.x, prev.y, next.x, next.y; untracked points carry NaN)
 __device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, int step, int g, float& px, float& py, float& cx, float& cy)
 {
+    if (gw == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(F + (size_t)g * 4);
+        px = v.x; py = v.y; cx = v.z; cy = v.w;
+        return;
+    }
     const int gy = g / gw, gx = g - gy * gw;
     px = (float)(gx * step);
     py = (float)(gy * step);
@@ -108,9 +117,10 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
     __shared__ Rng s_rng;
 
     const int pair = blockIdx.x, tid = threadIdx.x;
-    const int total = a.gh * a.gw;
-    const float* __restrict__ F = a.grid_flow + (size_t)pair * total * 2;
-    int* __restrict__ vmap = a.vmap + (size_t)pair * total;
+    const bool points = a.gw == 0;
+    const int total = points ? a.counts[pair] : a.gh * a.gw;
+    const float* __restrict__ F = a.grid_flow + (size_t)pair * a.cap * (points ? 4 : 2);
+    int* __restrict__ vmap = a.vmap + (size_t)pair * a.cap;
     vstab_fit_record* out = a.out + (size_t)pair * 3;
 
     // ---- validity scan (ordered compaction, flow.py:150-152) ----
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
     }
     __syncthreads();
     if (tid < 3) identity_record(out[tid], nv, total);
-    if (nv < 12) return;   // flow.py:153-154 (block-uniform)
+    if (points ? (total < 12 || nv < 8) : nv < 12) return;   // flow.py:153-154 / classic.py:84-86,102-103 (block-uniform)
     __threadfence_block();
     __syncthreads();
 
@@ -331,7 +341,33 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
 }  // namespace
 
 int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
-                         vstab_fit_record* d_out);
+                         int cap, vstab_fit_record* d_out);
+
+static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pairs, int gh, int gw, int step, int cap,
+                   int requested_mode, vstab_fit_record* results)
+{
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const size_t rec_bytes = sizeof(vstab_fit_record) * (size_t)pairs * 3;
+    const size_t map_bytes = sizeof(int) * (size_t)pairs * cap;
+    if (ctx->d_fit.reserve(rec_bytes + map_bytes + 512)) return 1;
+    if (ctx->h_fit.reserve(rec_bytes)) return 1;
+    char* base = static_cast<char*>(ctx->d_fit.ptr);
+    vstab_fit_record* d_out = reinterpret_cast<vstab_fit_record*>(base);
+    int* d_map = reinterpret_cast<int*>(base + ((rec_bytes + 255) & ~size_t(255)));
+    {
+        KernelTimer timer(ctx, "fit");
+        FitArgs a{data, d_map, d_out, pairs, gh, gw, step, requested_mode, counts, cap};
+        hipLaunchKernelGGL(fit_kernel, dim3((unsigned)pairs), dim3(FIT_THREADS), 0, ctx->stream, a);
+        VSTAB_HIP(hipGetLastError());
+        if (requested_mode >= VSTAB_MODE_PERSPECTIVE) {
+            if (int rc = vstab_fit_homography(ctx, data, d_map, pairs, gh, gw, step, cap, d_out)) return rc;
+        }
+    }
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(results, ctx->h_fit.ptr, rec_bytes);
+    return 0;
+}
 
 extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw, int step,
                                       int requested_mode, vstab_fit_record* results)
@@ -341,26 +377,16 @@ extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, in
     VSTAB_REQUIRE(pairs > 0 && gh > 0 && gw > 0 && step > 0, "vstab_sample_fit_batch: non-positive size");
     VSTAB_REQUIRE(requested_mode >= VSTAB_MODE_TRANSLATION && requested_mode <= VSTAB_MODE_PERSPECTIVE, "vstab_sample_fit_batch: unknown mode %d", requested_mode);
     VSTAB_REQUIRE((long long)gh * gw <= MAX_SORT, "vstab_sample_fit_batch: %d sample points exceed the supported %d", gh * gw, MAX_SORT);
-    VSTAB_HIP(hipSetDevice(ctx->device));
-    const size_t rec_bytes = sizeof(vstab_fit_record) * (size_t)pairs * 3;
-    const size_t map_bytes = sizeof(int) * (size_t)pairs * gh * gw;
-    if (ctx->d_fit.reserve(rec_bytes + map_bytes + 512)) return 1;
-    if (ctx->h_fit.reserve(rec_bytes)) return 1;
-    char* base = static_cast<char*>(ctx->d_fit.ptr);
-    vstab_fit_record* d_out = reinterpret_cast<vstab_fit_record*>(base);
-    int* d_map = reinterpret_cast<int*>(base + ((rec_bytes + 255) & ~size_t(255)));
-    {
-        KernelTimer timer(ctx, "fit");
-        FitArgs a{grid_flow, d_map, d_out, pairs, gh, gw, step, requested_mode};
-        hipLaunchKernelGGL(fit_kernel, dim3((unsigned)pairs), dim3(FIT_THREADS), 0, ctx->stream, a);
-        VSTAB_HIP(hipGetLastError());
-        if (requested_mode >= VSTAB_MODE_PERSPECTIVE) {
-            if (int rc = vstab_fit_homography(ctx, grid_flow, d_map, pairs, gh, gw, step, d_out)) return rc;
-        }
-    }
-    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(results, ctx->h_fit.ptr, rec_bytes);
-    return 0;
+    return run_fit(ctx, grid_flow, nullptr, pairs, gh, gw, step, gh * gw, requested_mode, results);
 }
 
+extern "C" int vstab_points_fit_batch(vstab_ctx* ctx, const float* point_pairs, const int* counts, int pairs, int max_points,
+                                      int requested_mode, vstab_fit_record* results)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_points_fit_batch: ctx is NULL");
+    VSTAB_REQUIRE(point_pairs && counts && results, "vstab_points_fit_batch: NULL pointer argument");
+    VSTAB_REQUIRE(pairs > 0 && max_points > 0, "vstab_points_fit_batch: non-positive size");
+    VSTAB_REQUIRE(requested_mode >= VSTAB_MODE_TRANSLATION && requested_mode <= VSTAB_MODE_PERSPECTIVE, "vstab_points_fit_batch: unknown mode %d", requested_mode);
+    VSTAB_REQUIRE(max_points <= MAX_SORT, "vstab_points_fit_batch: %d points per pair exceed the supported %d", max_points, MAX_SORT);
+    return run_fit(ctx, point_pairs, counts, pairs, 0, 0, 1, max_points, requested_mode, results);
+}

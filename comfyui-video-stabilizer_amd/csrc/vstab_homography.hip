@@ -39,8 +39,15 @@ __device__ int update_num_iters(double p, double ep, int modelPoints, int maxIte
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)__builtin_rint(num / denom);
 }
 
+// gw > 0: stride-`step` grid over a flow field (F = [gh][gw][2] displacements, flow.py:141-147);
+// gw == 0: explicit point pairs (F = [cap][4]: prev.x, prev.y, next.x, next.y; untracked points carry NaN)
 __device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, int step, int g, float& px, float& py, float& cx, float& cy)
 {
+    if (gw == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(F + (size_t)g * 4);
+        px = v.x; py = v.y; cx = v.z; cy = v.w;
+        return;
+    }
     const int gy = g / gw, gx = g - gy * gw;
     px = (float)(gx * step);
     py = (float)(gy * step);
@@ -262,6 +269,7 @@ struct HArgs {
     const int* vmap;
     vstab_fit_record* out;
     int pairs, gh, gw, step;
+    int cap;   // row stride (entries) of grid_flow / vmap per pair
 };
 
 // residuals + (optionally) the normal equations of HomographyRefineCallback for parameters h[8] over the inliers
@@ -332,12 +340,13 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
     __shared__ Rng s_rng;
 
     const int pair = blockIdx.x, tid = threadIdx.x;
-    const int total = a.gh * a.gw;
-    const float* __restrict__ F = a.grid_flow + (size_t)pair * total * 2;
-    const int* __restrict__ vmap = a.vmap + (size_t)pair * total;
+    const bool points = a.gw == 0;
+    const float* __restrict__ F = a.grid_flow + (size_t)pair * a.cap * (points ? 4 : 2);
+    const int* __restrict__ vmap = a.vmap + (size_t)pair * a.cap;
     vstab_fit_record* out = a.out + (size_t)pair * 3 + VSTAB_MODE_PERSPECTIVE;
     const int nv = a.out[(size_t)pair * 3].valid_points;
-    if (nv < 12) return;   // flow.py:153-154 (record stays "not computed")
+    // flow.py:153-154 / classic.py:84-86,102-103 (record stays "not computed")
+    if (points ? (a.out[(size_t)pair * 3].total_points < 12 || nv < 8) : nv < 12) return;
     const float thr = (float)(2.5 * 2.5);
 
     if (tid == 0) { s_rng.state = ~0ULL; s_ctl[0] = 0; s_ctl[1] = 2000; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[4] = 0; }
@@ -589,9 +598,9 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
 }  // namespace
 
 int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
-                         vstab_fit_record* d_out)
+                         int cap, vstab_fit_record* d_out)
 {
-    HArgs a{grid_flow, vmap, d_out, pairs, gh, gw, step};
+    HArgs a{grid_flow, vmap, d_out, pairs, gh, gw, step, cap};
     hipLaunchKernelGGL(homography_kernel, dim3((unsigned)pairs), dim3(HT), 0, ctx->stream, a);
     VSTAB_HIP(hipGetLastError());
     return 0;

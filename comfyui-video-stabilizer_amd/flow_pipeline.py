@@ -42,11 +42,21 @@ class _gc_paused:
         return False
 
 
-def _attach_motion_meta(meta: Dict[str, Any], fps: float) -> Dict[str, Any]:
+# The Classic node (nodes/video_stabilizer_classic.py) shares this pipeline; only the estimator and a few
+# meta keys differ: no flow_backend / flow_fallback_reason (classic.py:189-208, 236-250, 336-360, 537-568),
+# no per-transition residual (classic.py:549-557), source "estimated_classic" (classic.py:57-61).
+_META_SOURCE = {"flow": "estimated_flow", "classic": "estimated_classic"}
+
+
+def _backend_fields(estimator: str) -> Dict[str, Any]:
+    return {"flow_backend": "DIS", "flow_fallback_reason": None} if estimator == "flow" else {}
+
+
+def _attach_motion_meta(meta: Dict[str, Any], fps: float, estimator: str = "flow") -> Dict[str, Any]:
     """flow.py:62-73: a failure to derive motion_meta is swallowed, the rest of the meta survives."""
     try:
         meta["motion_meta"] = applied_motion_meta_from_stabilization_warp(
-            meta["stabilization_warp"], fps=fps, source="estimated_flow")
+            meta["stabilization_warp"], fps=fps, source=_META_SOURCE[estimator])
     except (KeyError, TypeError, ValueError, np.linalg.LinAlgError):
         pass
     return meta
@@ -118,6 +128,20 @@ def estimate_transitions(ctx, device_frames, working_size, transform_mode: str, 
     return ctx.sample_fit_batch(grid, SAMPLE_STEP, transform_mode)
 
 
+# classic.py:76-96: cv2.goodFeaturesToTrack / cv2.calcOpticalFlowPyrLK arguments of the Classic node
+CLASSIC_GFTT = dict(max_corners=400, quality=0.01, min_distance=7.0, block_size=21)
+CLASSIC_LK = dict(win=31, max_level=3, max_count=50, epsilon=0.01)
+
+
+def estimate_transitions_classic(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
+    """Classic estimator (classic.py:69-160) for frames [N,H,W,3] on the device -> candidate fits [N-1,3]:
+    corners of frame i (HIP) -> pyramidal LK into frame i+1 (HIP) -> model fits on the tracked pairs (HIP)."""
+    gray = ctx.gray_downscale(device_frames, working_size)
+    corners, counts = ctx.gftt_batch(gray[:-1], **CLASSIC_GFTT)
+    pairs = ctx.lk_track_batch(gray, corners, counts, **CLASSIC_LK)
+    return ctx.points_fit_batch(pairs, counts, transform_mode)
+
+
 def _fps_fields(context: hm.VideoContext, frame_rate) -> Tuple[float, Optional[float]]:
     cand = frame_rate
     if not isinstance(cand, (int, float)) or not np.isfinite(cand) or cand <= 0.0:
@@ -148,6 +172,7 @@ class FlowPlan:
     source_size: Tuple[int, int]
     fps_effective: float
     bypass_meta: Optional[Dict[str, Any]] = None
+    estimator: str = "flow"
 
 
 def plan_stabilization(*args, **kwargs) -> "FlowPlan":
@@ -156,12 +181,11 @@ def plan_stabilization(*args, **kwargs) -> "FlowPlan":
 
 
 def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
-                       keep_fov, padding_rgb, fps_effective, fps_requested) -> FlowPlan:
+                       keep_fov, padding_rgb, fps_effective, fps_requested, estimator: str = "flow") -> FlowPlan:
     """flow.py:324-546 for a whole clip: sticky-mode selection, parameter deltas, trajectory (HIP fp64),
     framing geometry.  `fit_records` covers all N-1 transitions of the clip."""
     width, height = size
     rgb_list = [int(c) for c in padding_rgb]
-    flow_backend, flow_fallback_reason = "DIS", None
     base_mode = transform_mode
     working_size = hm._working_estimation_size(width, height)
     work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
@@ -205,8 +229,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
                     "stabilization_scale": 0.0,
                 },
                 "keep_fov_applied": False,
-                "flow_backend": flow_backend,
-                "flow_fallback_reason": flow_fallback_reason,
+                **_backend_fields(estimator),
                 "stabilization_warp": hm._build_stabilization_warp_meta(
                     source_size=size, output_size=size, framing_mode=framing_mode,
                     applied_matrices=[np.eye(3, dtype=np.float32) for _ in range(total_frames)]),
@@ -219,7 +242,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
                 "padding_fraction_mean": 0.0,
                 "padding_fraction_max": 0.0,
             }
-            return FlowPlan([], size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta)
+            return FlowPlan([], size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta, estimator=estimator)
         # flow.py:431-470: keep_fov solver, then the padding-free refinement
         from .crop_solver import solve_crop
 
@@ -289,14 +312,14 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         "fps_effective": fps_effective,
         "keep_fov_applied": keep_fov_applied,
         "padding_color_rgb": rgb_list,
-        "flow_backend": flow_backend,
-        "flow_fallback_reason": flow_fallback_reason,
+        **_backend_fields(estimator),
     }
     estimated_motion = {   # arrays; turned into JSON lists by prepare_meta (off the critical path)
         "modes": modes_used, "confidences": confidences, "residuals": residuals, "matrices": matrices,
         "path": path, "target_path": target_path, "target_path_effective": effective_target_path,
     }
-    return FlowPlan(final_matrices, output_size, meta_head, framing_meta, estimated_motion, framing_mode, size, fps_effective)
+    return FlowPlan(final_matrices, output_size, meta_head, framing_meta, estimated_motion, framing_mode, size, fps_effective,
+                    estimator=estimator)
 
 
 def prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
@@ -323,8 +346,7 @@ def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
         "framing": dict(plan.framing_meta),
         "keep_fov_applied": h["keep_fov_applied"],
         "padding_color_rgb": h["padding_color_rgb"],
-        "flow_backend": h["flow_backend"],
-        "flow_fallback_reason": h["flow_fallback_reason"],
+        **_backend_fields(plan.estimator),
         "stabilization_warp": hm._build_stabilization_warp_meta(
             source_size=plan.source_size, output_size=plan.output_size, framing_mode=plan.framing_mode,
             applied_matrices=final_stack),
@@ -333,6 +355,10 @@ def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
                 {"index": i, "mode": mode, "confidence": conf, "residual": resid, "matrix": mat}
                 for i, (mode, conf, resid, mat) in enumerate(zip(em["modes"], em["confidences"], em["residuals"],
                                                                  np.asarray(em["matrices"], dtype=np.float32).tolist()))
+            ] if plan.estimator == "flow" else [
+                {"index": i, "mode": mode, "confidence": conf, "matrix": mat}
+                for i, (mode, conf, mat) in enumerate(zip(em["modes"], em["confidences"],
+                                                          np.asarray(em["matrices"], dtype=np.float32).tolist()))
             ],
             "path": em["path"].tolist(),
             "target_path": em["target_path"].tolist(),
@@ -341,11 +367,12 @@ def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
         "padding_fraction_mean": None,
         "padding_fraction_max": None,
     }
-    fast = applied_motion_meta_from_arrays(final_stack, plan.source_size, plan.output_size, plan.fps_effective, "estimated_flow")
+    fast = applied_motion_meta_from_arrays(final_stack, plan.source_size, plan.output_size, plan.fps_effective,
+                                           _META_SOURCE[plan.estimator])
     if fast is not None:
         meta["motion_meta"] = fast
         return meta
-    return _attach_motion_meta(meta, plan.fps_effective)
+    return _attach_motion_meta(meta, plan.fps_effective, plan.estimator)
 
 
 def complete_meta(meta: Dict[str, Any], plan: FlowPlan, pad_counts) -> Dict[str, Any]:
@@ -376,14 +403,17 @@ def _stabilize_frames(
     *,
     ctx: Optional[native.Context] = None,
     keep_on_device: bool = False,
+    estimator: str = "flow",
 ) -> hm.StabilizationResult:
     """Positional signature of the reference (flow.py:213-223); keyword-only extras select the GPU
-    context or keep outputs resident in HBM (multi-GPU sharding lives in distributed.py)."""
+    context, keep outputs resident in HBM (multi-GPU sharding lives in distributed.py) or switch the
+    motion estimator to the Classic node's sparse tracker (classic.py:163-173, same signature)."""
+    if estimator not in _META_SOURCE:
+        raise ValueError(f"Unknown estimator {estimator!r}; expected 'flow' or 'classic'.")
     total_frames = len(context.frames)
     fps_effective, fps_requested = _fps_fields(context, frame_rate)
     size = (context.width, context.height)
     rgb_list = [int(c) for c in padding_rgb]
-    flow_backend, flow_fallback_reason = "DIS", None
 
     if total_frames == 0:  # unreachable through the node (flow.py:242-273)
         meta = {
@@ -400,15 +430,14 @@ def _stabilize_frames(
             "framing": {"mode": framing_mode, "input_size": list(size), "padding_color_rgb": rgb_list},
             "keep_fov_applied": False,
             "padding_color_rgb": rgb_list,
-            "flow_backend": flow_backend,
-            "flow_fallback_reason": flow_fallback_reason,
+            **_backend_fields(estimator),
             "stabilization_warp": hm._build_stabilization_warp_meta(
                 source_size=size, output_size=size, framing_mode=framing_mode, applied_matrices=[]),
             "estimated_motion": {"per_transition": [], "path": [], "target_path": [], "target_path_effective": []},
             "padding_fraction_mean": 0.0,
             "padding_fraction_max": 0.0,
         }
-        return hm.StabilizationResult([], [], _attach_motion_meta(meta, fps_effective))
+        return hm.StabilizationResult([], [], _attach_motion_meta(meta, fps_effective, estimator))
 
     progress_total = max(0, total_frames - 1) + total_frames
     pbar = ProgressBar(progress_total)
@@ -419,9 +448,8 @@ def _stabilize_frames(
             "note": "Single-frame input; bypassed stabilization.",
             "transform_mode": transform_mode,
             "framing_mode": framing_mode,
-            "keep_fov_applied": False,
-            "flow_backend": flow_backend,
-            "flow_fallback_reason": flow_fallback_reason,
+            **({"keep_fov_applied": False} if estimator == "flow" else {}),   # flow.py:297 only; classic.py:236-250 has no such key
+            **_backend_fields(estimator),
             "stabilization_warp": hm._build_stabilization_warp_meta(
                 source_size=size, output_size=size, framing_mode=framing_mode,
                 applied_matrices=[np.eye(3, dtype=np.float32)]),
@@ -431,25 +459,26 @@ def _stabilize_frames(
         pbar.update_absolute(progress_total, progress_total)
         frames_out = _host_frames(context)
         masks_out = np.zeros((1, context.height, context.width, 1), np.float32)
-        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(meta, fps_effective))
+        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(meta, fps_effective, estimator))
 
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
     working_size = hm._working_estimation_size(context.width, context.height)
 
     # ---- estimation (F2-F5) -------------------------------------------------
-    fit_records = estimate_transitions(ctx, device_frames, working_size, transform_mode)
+    estimate = estimate_transitions if estimator == "flow" else estimate_transitions_classic
+    fit_records = estimate(ctx, device_frames, working_size, transform_mode)
     progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
     check_interrupt()
 
     plan = plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength,
-                              smooth, keep_fov, padding_rgb, fps_effective, fps_requested)
+                              smooth, keep_fov, padding_rgb, fps_effective, fps_requested, estimator=estimator)
     if plan.bypass_meta is not None:  # crop + keep_fov ~ 1 (flow.py:387-429): original frames
         pbar.update_absolute(progress_total, progress_total)
         frames_out = device_frames if keep_on_device else _host_frames(context)
         masks_out = (ctx.torch.zeros((total_frames, context.height, context.width, 1), device=ctx.device)
                      if keep_on_device else np.zeros((total_frames, context.height, context.width, 1), np.float32))
-        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(plan.bypass_meta, fps_effective))
+        return hm.StabilizationResult(frames_out, masks_out, _attach_motion_meta(plan.bypass_meta, fps_effective, estimator))
 
     # ---- warp (F13) ------------------------------------------------------------
     dst, mask, counts = ctx.warp_batch(

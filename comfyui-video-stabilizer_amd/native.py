@@ -117,6 +117,15 @@ _SIGNATURES = {
     "vstab_dis_set_clip_start": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_sample_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_gftt_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                  C.c_void_p]),
+    "vstab_lk_levels": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vstab_lk_track_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                  C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vstab_points_fit_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_crop_analysis": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_trajectory": (
@@ -322,6 +331,57 @@ class Context:
                 self.handle, _dev_ptr(grid_flow), pairs, gh, gw, int(step), MODES[requested_mode], table.ctypes.data),
             "vstab_sample_fit_batch",
         )
+        return table
+
+    # ------------------------------------------------------------------ Classic estimator (sparse features + LK)
+    def gftt_batch(self, gray, max_corners=400, quality=0.01, min_distance=7.0, block_size=21):
+        """gray u8 [N,h,w] (device) -> (corners [N,max_corners,2] f32, counts [N] i32), both on the device."""
+        torch = self.torch
+        if gray.device != self.device:
+            gray = gray.to(self.device)
+        gray = gray.contiguous()
+        n, h, w = gray.shape
+        corners = torch.zeros((n, int(max_corners), 2), dtype=torch.float32, device=self.device)
+        counts = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self.use_torch_stream()
+        _check(self.lib.vstab_gftt_batch(self.handle, _dev_ptr(gray), n, h, w, int(max_corners), float(quality),
+                                         float(min_distance), int(block_size), _dev_ptr(corners), _dev_ptr(counts)),
+               "vstab_gftt_batch")
+        return corners, counts
+
+    def lk_track_batch(self, gray, points, counts, win=31, max_level=3, max_count=50, epsilon=0.01, want_raw=False):
+        """Track points[i] (features of frame i) from frame i to frame i+1 for the N-1 pairs of gray [N,h,w].
+        Returns point_pairs [N-1,max,4] (next = NaN where untracked) and, with want_raw, (next [N-1,max,2], status)."""
+        torch = self.torch
+        gray = gray.contiguous()
+        n, h, w = gray.shape
+        pairs = n - 1
+        if pairs < 1:
+            raise VstabError("lk_track_batch needs at least two frames")
+        points = points[:pairs].contiguous()
+        counts = counts[:pairs].contiguous()
+        max_pts = int(points.shape[1])
+        out = torch.empty((pairs, max_pts, 4), dtype=torch.float32, device=self.device)
+        nxt = torch.zeros((pairs, max_pts, 2), dtype=torch.float32, device=self.device) if want_raw else None
+        status = torch.zeros((pairs, max_pts), dtype=torch.uint8, device=self.device) if want_raw else None
+        self.use_torch_stream()
+        _check(self.lib.vstab_lk_track_batch(self.handle, _dev_ptr(gray), n, h, w, _dev_ptr(points), _dev_ptr(counts), max_pts,
+                                             int(win), int(max_level), int(max_count), float(epsilon), _dev_ptr(out),
+                                             _dev_ptr(nxt) if nxt is not None else None,
+                                             _dev_ptr(status) if status is not None else None),
+               "vstab_lk_track_batch")
+        return (out, nxt, status) if want_raw else out
+
+    def points_fit_batch(self, point_pairs, counts, requested_mode):
+        """point_pairs [P,max,4] + counts [P] (device) -> structured table [P,3] (FIT_DTYPE)."""
+        point_pairs = point_pairs.contiguous()
+        counts = counts[: point_pairs.shape[0]].contiguous()
+        pairs, max_pts, _ = point_pairs.shape
+        table = np.zeros((pairs, 3), FIT_DTYPE)
+        self.use_torch_stream()
+        _check(self.lib.vstab_points_fit_batch(self.handle, _dev_ptr(point_pairs), _dev_ptr(counts), pairs, max_pts,
+                                               MODES[requested_mode], table.ctypes.data),
+               "vstab_points_fit_batch")
         return table
 
     def crop_analysis(self, matrices, src_size, out_size):

@@ -41,6 +41,50 @@ def _mask_out(masks):
     return hm._convert_masks_for_output(masks)
 
 
+def _estimator_inputs(transform_tip: str, lock_tip: str, framing_tip: str, strength_tip: str, smooth_tip: str) -> list:
+    """The nine input sockets shared by the Flow and Classic nodes (flow.py:657-726, classic.py:586-659):
+    same ids, order, defaults and ranges; only some tooltips differ."""
+    slider = io.NumberDisplay.slider
+    return [
+        io.Image.Input("frames", display_name="Frames"),
+        io.Float.Input("frame_rate", default=16.0, min=1.0, step=0.1, display_name="Input FPS",
+                       tooltip="Frame rate in frames per second used to scale smoothing window."),
+        io.Combo.Input("framing_mode", options=["crop", "crop_and_pad", "expand"], default="crop_and_pad",
+                       display_name="Framing Mode", tooltip=framing_tip),
+        io.Combo.Input("transform_mode", options=["translation", "similarity", "perspective"],
+                       default="similarity", display_name="Transform Mode", tooltip=transform_tip),
+        io.Boolean.Input("camera_lock", default=False, display_name="Camera Lock", tooltip=lock_tip),
+        io.Float.Input("strength", default=0.7, min=0.0, max=1.0, step=0.05, display_name="Strength",
+                       tooltip=strength_tip, display_mode=slider),
+        io.Float.Input("smooth", default=0.5, min=0.0, max=1.0, step=0.05, display_name="Smooth",
+                       tooltip=smooth_tip, display_mode=slider),
+        io.Float.Input("keep_fov", default=0.6, min=0.0, max=1.0, step=0.05, display_name="Keep FOV",
+                       tooltip=("[Crop only] How much of the original FOV to preserve (1.0 = no zoom, 0.0 = maximum "
+                                "zoom). Ignored when framing_mode is crop_and_pad or expand."),
+                       display_mode=slider),
+        io.Color.Input("padding_color", default="#7F7F7F", display_name="Padding Color",
+                       tooltip="HEX padding color applied in crop_and_pad / expand (e.g. #404040)."),
+    ]
+
+
+def _estimator_outputs() -> list:
+    return [
+        io.Image.Output("frames_stabilized", display_name="Stabilized Frames"),
+        io.Mask.Output("padding_mask", display_name="Padding Mask"),
+        JSONType.Output("meta", display_name="Motion Meta"),
+    ]
+
+
+def _run_estimator_node(estimator: str, frames: Any, frame_rate: float, framing_mode: str, transform_mode: str,
+                        camera_lock: bool, strength: float, smooth: float, keep_fov: float, padding_color: str):
+    context = hm._normalize_video_input(frames)
+    result = _stabilize_frames(
+        context, framing_mode, transform_mode, camera_lock, strength, smooth, keep_fov,
+        hm._parse_padding_color(padding_color), frame_rate, keep_on_device=True, estimator=estimator,
+    )
+    return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
+
+
 class VideoStabilizerFlow(io.ComfyNode):
     """Dense-flow (DIS) stabilizer; all pixel work runs on the MI355X through libvstab."""
 
@@ -55,48 +99,53 @@ class VideoStabilizerFlow(io.ComfyNode):
                 "emitting stabilized frames, a padding mask, and motion diagnostics (MI355X build)."
             ),
         )
-        slider = io.NumberDisplay.slider
-        schema.inputs = [
-            io.Image.Input("frames", display_name="Frames"),
-            io.Float.Input("frame_rate", default=16.0, min=1.0, step=0.1, display_name="Input FPS",
-                           tooltip="Frame rate in frames per second used to scale smoothing window."),
-            io.Combo.Input("framing_mode", options=["crop", "crop_and_pad", "expand"], default="crop_and_pad",
-                           display_name="Framing Mode",
-                           tooltip="Choose how borders produced by stabilization are handled."),
-            io.Combo.Input("transform_mode", options=["translation", "similarity", "perspective"],
-                           default="similarity", display_name="Transform Mode",
-                           tooltip="Select the geometric model fitted to the optical flow."),
-            io.Boolean.Input("camera_lock", default=False, display_name="Camera Lock",
-                             tooltip="Aggressively pull the motion curve toward a locked tripod-like solution."),
-            io.Float.Input("strength", default=0.7, min=0.0, max=1.0, step=0.05, display_name="Strength",
-                           tooltip="Removal gain (0 keeps original motion, 1 removes it using the smoothed motion curve).",
-                           display_mode=slider),
-            io.Float.Input("smooth", default=0.5, min=0.0, max=1.0, step=0.05, display_name="Smooth",
-                           tooltip="Temporal smoothing amount applied to the motion curve before removal.",
-                           display_mode=slider),
-            io.Float.Input("keep_fov", default=0.6, min=0.0, max=1.0, step=0.05, display_name="Keep FOV",
-                           tooltip=("[Crop only] How much of the original FOV to preserve (1.0 = no zoom, 0.0 = maximum "
-                                    "zoom). Ignored when framing_mode is crop_and_pad or expand."),
-                           display_mode=slider),
-            io.Color.Input("padding_color", default="#7F7F7F", display_name="Padding Color",
-                           tooltip="HEX padding color applied in crop_and_pad / expand (e.g. #404040)."),
-        ]
-        schema.outputs = [
-            io.Image.Output("frames_stabilized", display_name="Stabilized Frames"),
-            io.Mask.Output("padding_mask", display_name="Padding Mask"),
-            JSONType.Output("meta", display_name="Motion Meta"),
-        ]
+        schema.inputs = _estimator_inputs(
+            transform_tip="Select the geometric model fitted to the optical flow.",
+            lock_tip="Aggressively pull the motion curve toward a locked tripod-like solution.",
+            framing_tip="Choose how borders produced by stabilization are handled.",
+            strength_tip="Removal gain (0 keeps original motion, 1 removes it using the smoothed motion curve).",
+            smooth_tip="Temporal smoothing amount applied to the motion curve before removal.",
+        )
+        schema.outputs = _estimator_outputs()
         return schema
 
     @classmethod
     def execute(cls, frames: Any, frame_rate: float, framing_mode: str, transform_mode: str, camera_lock: bool,
                 strength: float, smooth: float, keep_fov: float, padding_color: str) -> io.NodeOutput:
-        context = hm._normalize_video_input(frames)
-        result = _stabilize_frames(
-            context, framing_mode, transform_mode, camera_lock, strength, smooth, keep_fov,
-            hm._parse_padding_color(padding_color), frame_rate, keep_on_device=True,
+        return _run_estimator_node("flow", frames, frame_rate, framing_mode, transform_mode, camera_lock, strength,
+                                   smooth, keep_fov, padding_color)
+
+
+class VideoStabilizerClassic(io.ComfyNode):
+    """Sparse feature-tracking stabilizer (corner detection + pyramidal LK, classic.py:69-160) -- same sockets
+    and meta as the reference's `Video Stabilizer Classic`; the tracker runs on the MI355X as well."""
+
+    @classmethod
+    def define_schema(cls) -> io.Schema:
+        schema = io.Schema(
+            node_id="video_stabilizer_classic",
+            display_name="Video Stabilizer Classic",
+            category="Video/Stabilization",
+            description=(
+                "Video stabilization using sparse feature tracking with configurable transforms and framing, "
+                "emitting both stabilized frames and a padding mask (MI355X build)."
+            ),
         )
-        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
+        schema.inputs = _estimator_inputs(
+            transform_tip="Select the geometric model used to estimate camera motion.",
+            lock_tip="Treat the shot as tripod-like by aggressively damping motion.",
+            framing_tip="Choose how to handle borders produced by stabilization.",
+            strength_tip="Removal gain (0 keeps original motion, 1 removes it based on smoothing).",
+            smooth_tip="Temporal smoothing amount applied to the estimated motion path.",
+        )
+        schema.outputs = _estimator_outputs()
+        return schema
+
+    @classmethod
+    def execute(cls, frames: Any, frame_rate: float, framing_mode: str, transform_mode: str, camera_lock: bool,
+                strength: float, smooth: float, keep_fov: float, padding_color: str) -> io.NodeOutput:
+        return _run_estimator_node("classic", frames, frame_rate, framing_mode, transform_mode, camera_lock, strength,
+                                   smooth, keep_fov, padding_color)
 
 
 class VideoStabilizerMotionApply(io.ComfyNode):
@@ -209,7 +258,7 @@ class VideoStabilizerInverse(io.ComfyNode):
         return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
 
 
-NODE_CLASSES = [VideoStabilizerFlow, VideoStabilizerMotionApply, VideoStabilizerInverse]
+NODE_CLASSES = [VideoStabilizerClassic, VideoStabilizerFlow, VideoStabilizerMotionApply, VideoStabilizerInverse]
 
 
 class VideoStabilizerAmdExtension(ComfyExtension):

@@ -155,6 +155,38 @@ int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, in
 int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w,
                         int out_h, int out_w, int32_t* bbox, uint8_t* common);
 
+/* ---- N1 (Classic estimator): sparse features + pyramidal LK ------------------
+ * Replaces nodes/video_stabilizer_classic.py:76-96 (`_estimate_motion_pair`) for a whole clip.
+ *
+ * vstab_gftt_batch: cv2.goodFeaturesToTrack(gray, maxCorners, qualityLevel, minDistance, blockSize)
+ * (classic.py:76-83: 400 / 0.01 / 7 / 21; no mask, min-eigenvalue score, 3x3 Sobel) on every frame.
+ *   gray    dev [n,h,w] u8
+ *   corners dev [n,max_corners,2] f32 (x, y), strongest first;  counts dev [n] i32
+ *
+ * vstab_lk_track_batch: cv2.calcOpticalFlowPyrLK(frame i, frame i+1, corners of frame i, None,
+ * winSize=(win,win), maxLevel, criteria=(EPS|COUNT, max_count, epsilon)) (classic.py:88-96: 31 / 3 /
+ * 50 / 0.01) for the n-1 consecutive pairs of the clip.
+ *   points      dev [n-1,max_points,2] f32, counts dev [n-1] i32 (rows of vstab_gftt_batch's output)
+ *   point_pairs dev [n-1,max_points,4] f32: prev.x, prev.y, next.x, next.y; next = NaN where the
+ *               tracker's status is 0 -- the input layout of vstab_points_fit_batch
+ *   next_points dev [n-1,max_points,2] f32 or NULL (raw tracker output, also for status 0)
+ *   status      dev [n-1,max_points] u8 or NULL
+ * vstab_lk_levels: number of pyramid levels above level 0 that buildOpticalFlowPyramid keeps.
+ *
+ * vstab_points_fit_batch: the model-fit cascade of classic.py:98-160 on the tracked pairs: fewer
+ * than 12 features or fewer than 8 tracked points -> no candidate; otherwise the same three
+ * estimators as vstab_sample_fit_batch (translation confidence = tracked / features).
+ *   results host [pairs*3] records indexed [pair*3 + mode] (residual is filled but unused by Classic)
+ */
+int vstab_gftt_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int max_corners,
+                     double quality, double min_distance, int block_size, float* corners, int* counts);
+int vstab_lk_levels(int h, int w, int win, int max_level);
+int vstab_lk_track_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, const float* points,
+                         const int* counts, int max_points, int win, int max_level, int max_count,
+                         double epsilon, float* point_pairs, float* next_points, uint8_t* status);
+int vstab_points_fit_batch(vstab_ctx* ctx, const float* point_pairs, const int* counts, int pairs,
+                           int max_points, int requested_mode, vstab_fit_record* results);
+
 /* ---- F7 + F8: trajectory (prefix sum, box smoothing, strength blend), fp64 ---
  * Replaces nodes/video_stabilizer_flow.py:356-371 and
  * nodes/stabilizer_utils.py:361-383 (_smooth_path: moving average, edge padded,

@@ -293,3 +293,104 @@ def crop_analysis(matrices, src_size, out_size):
     common = np.zeros((oh, ow), np.uint8)
     lib().vo_crop_analysis(_ptr(m, C.c_float), n, sh, sw, oh, ow, _ptr(bbox, C.c_int32), _ptr(common, C.c_uint8))
     return bbox, common
+
+
+# ---------------------------------------------------------------- Classic estimator (GFTT + pyramidal LK)
+GFTT = dict(max_corners=400, quality=0.01, min_distance=7.0, block=21)   # classic.py:76-83
+LK = dict(win=31, max_level=3, max_count=50, epsilon=0.01)               # classic.py:88-96
+
+
+def min_eigen_val(gray, block=21):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    eig = np.empty((h, w), np.float32)
+    lib().vo_min_eigen_val(_ptr(gray, C.c_uint8), h, w, int(block), _ptr(eig, C.c_float))
+    return eig
+
+
+def good_features(gray, max_corners=400, quality=0.01, min_distance=7.0, block=21):
+    """cv2.goodFeaturesToTrack(gray, ...) -> [n,2] f32 (x, y), strongest first."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    cap = max_corners if max_corners > 0 else h * w
+    pts = np.zeros((cap, 2), np.float32)
+    fn = lib().vo_good_features
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    n = fn(gray.ctypes.data, h, w, int(max_corners), float(quality), float(min_distance), int(block), pts.ctypes.data)
+    return pts[:n].copy()
+
+
+def pyr_down(gray):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().vo_pyr_down_u8(_ptr(gray, C.c_uint8), h, w, _ptr(out, C.c_uint8))
+    return out
+
+
+def scharr_deriv(gray):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    out = np.empty((h, w, 2), np.int16)
+    lib().vo_scharr_deriv(_ptr(gray, C.c_uint8), h, w, _ptr(out, C.c_int16))
+    return out
+
+
+def lk_levels(h, w, win=31, max_level=3):
+    return int(lib().vo_lk_levels(int(h), int(w), int(win), int(max_level)))
+
+
+def lk_track(prev, nxt, pts, win=31, max_level=3, max_count=50, epsilon=0.01):
+    """cv2.calcOpticalFlowPyrLK(prev, nxt, pts, None, winSize=(win,win), maxLevel, criteria) -> (next [n,2], status [n])."""
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
+    pts = _f32(pts).reshape(-1, 2)
+    h, w = prev.shape
+    n = pts.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    status = np.zeros(n, np.uint8)
+    fn = lib().vo_lk_track
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                   C.c_void_p, C.c_void_p]
+    fn(prev.ctypes.data, nxt.ctypes.data, h, w, pts.ctypes.data, n, int(win), int(max_level), int(max_count), float(epsilon),
+       out.ctypes.data, status.ctypes.data)
+    return out, status
+
+
+def fit_all_modes_points(prev_pts, next_pts, status, requested_mode="similarity"):
+    """Candidate fits of classic.py:105-160 on tracked points; same record layout as fit_all_modes."""
+    prev_pts, next_pts = _f32(prev_pts).reshape(-1, 2), _f32(next_pts).reshape(-1, 2)
+    status = np.ascontiguousarray(status, dtype=np.uint8)
+    recs = (FitResult * 3)()
+    nv = C.c_int()
+    fn = lib().vo_fit_all_modes_points
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(prev_pts.ctypes.data, next_pts.ctypes.data, status.ctypes.data, prev_pts.shape[0], MODES[requested_mode], recs, C.byref(nv))
+    out = {}
+    for mi in range(3):
+        r = recs[mi]
+        if r.mode < 0:
+            continue
+        out[MODE_NAMES[mi]] = {
+            "matrix": np.array(list(r.matrix), np.float32).reshape(3, 3),
+            "confidence": float(r.confidence),
+            "residual": float(r.residual),
+            "accepted": bool(r.valid),
+        }
+    return out, int(nv.value)
+
+
+def classic_estimate_pair(prev_gray, curr_gray, requested_mode="similarity"):
+    """_estimate_motion_pair (classic.py:69-160): (matrix f32 3x3, used mode, confidence)."""
+    feats = good_features(prev_gray, **GFTT)
+    if feats.shape[0] < 12:
+        return np.eye(3, dtype=np.float32), "translation", 0.0
+    nxt, status = lk_track(prev_gray, curr_gray, feats, **LK)
+    cands, _ = fit_all_modes_points(feats, nxt, status, requested_mode)
+    order = {"perspective": ["perspective", "similarity", "translation"], "similarity": ["similarity", "translation"],
+             "translation": ["translation"]}[requested_mode]
+    for mode in order:
+        c = cands.get(mode)
+        if c is not None and c["accepted"]:
+            return c["matrix"], mode, c["confidence"]
+    return np.eye(3, dtype=np.float32), "translation", 0.0

@@ -566,6 +566,18 @@ static float median_f32(float* v, int n)
 }
 
 /* Evaluates every mode at or below `requested`; rec[mode] as vo_fit_result with valid = accepted. */
+/* candidate fits of every mode at or below `requested_mode` on nv point pairs (flow.py:156-210, classic.py:105-160) */
+static void fit_modes_on_points(const float* prev, const float* curr, int nv, int total, int requested_mode, vo_fit_result* rec);
+
+static void reset_records(vo_fit_result* rec)
+{
+    for (int m = 0; m < 3; m++) {
+        memset(&rec[m], 0, sizeof(rec[m]));
+        rec[m].matrix[0] = rec[m].matrix[4] = rec[m].matrix[8] = 1.f;
+        rec[m].mode = -1; /* not computed */
+    }
+}
+
 void vo_fit_all_modes(const float* flow, int h, int w, int step, int requested_mode, vo_fit_result* rec /*3*/,
                       int* valid_points, int* total_points)
 {
@@ -587,12 +599,33 @@ void vo_fit_all_modes(const float* flow, int h, int w, int step, int requested_m
         }
     *valid_points = nv;
     *total_points = total;
-    for (int m = 0; m < 3; m++) {
-        memset(&rec[m], 0, sizeof(rec[m]));
-        rec[m].matrix[0] = rec[m].matrix[4] = rec[m].matrix[8] = 1.f;
-        rec[m].mode = -1; /* not computed */
-    }
-    if (nv < 12) { free(prev); free(curr); return; }
+    reset_records(rec);
+    if (nv >= 12) fit_modes_on_points(prev, curr, nv, total, requested_mode, rec);   /* flow.py:153-154 */
+    free(prev); free(curr);
+}
+
+/* Classic estimator (classic.py:86-104): `count` detected features, status from the LK tracker.
+ * Fewer than 12 features or fewer than 8 tracked ones -> no candidate at all. */
+void vo_fit_all_modes_points(const float* from, const float* to, const uint8_t* status, int count, int requested_mode,
+                             vo_fit_result* rec /*3*/, int* valid_points)
+{
+    float* prev = (float*)malloc(sizeof(float) * 2 * (count > 0 ? count : 1));
+    float* curr = (float*)malloc(sizeof(float) * 2 * (count > 0 ? count : 1));
+    int nv = 0;
+    for (int i = 0; i < count; i++)
+        if (status[i] == 1) {
+            prev[nv * 2] = from[i * 2]; prev[nv * 2 + 1] = from[i * 2 + 1];
+            curr[nv * 2] = to[i * 2]; curr[nv * 2 + 1] = to[i * 2 + 1];
+            nv++;
+        }
+    *valid_points = nv;
+    reset_records(rec);
+    if (count >= 12 && nv >= 8) fit_modes_on_points(prev, curr, nv, count, requested_mode, rec);
+    free(prev); free(curr);
+}
+
+static void fit_modes_on_points(const float* prev, const float* curr, int nv, int total, int requested_mode, vo_fit_result* rec)
+{
     uint8_t* inl = (uint8_t*)malloc(nv);
     if (requested_mode >= VO_MODE_PERSPECTIVE && nv >= 4) {
         double H[9];
@@ -657,7 +690,7 @@ void vo_fit_all_modes(const float* flow, int h, int w, int step, int requested_m
         r->valid = 1;
         free(sx); free(sy);
     }
-    free(inl); free(prev); free(curr);
+    free(inl);
 }
 
 void vo_fit_from_flow(const float* flow, int h, int w, int step, int requested_mode, vo_fit_result* out)

@@ -74,12 +74,24 @@ void vo_fit_from_flow(const float* flow, int h, int w, int step, int requested_m
 void vo_fit_all_modes(const float* flow, int h, int w, int step, int requested_mode,
                       vo_fit_result* rec /*3, indexed by mode; rec[m].mode == -1: not computed*/,
                       int* valid_points, int* total_points);
+void vo_fit_all_modes_points(const float* from, const float* to, const uint8_t* status, int count, int requested_mode,
+                             vo_fit_result* rec /*3*/, int* valid_points);
 int vo_estimate_affine_partial2d(const float* from, const float* to, int count, double thresh,
                                  int max_iters, double confidence, int refine_iters,
                                  double* M /*2x3*/, uint8_t* inliers);
 int vo_find_homography_ransac(const float* from, const float* to, int count, double thresh,
                               int max_iters, double confidence, double* H /*3x3*/,
                               uint8_t* inliers);
+
+/* ---- Classic estimator: GFTT + pyramidal LK (vo_classic.c) ---- */
+void vo_min_eigen_val(const uint8_t* img, int h, int w, int block, float* eig);
+int vo_good_features(const uint8_t* img, int h, int w, int max_corners, double quality, double min_distance,
+                     int block, float* corners /*[max_corners][2]*/);
+void vo_pyr_down_u8(const uint8_t* src, int sh, int sw, uint8_t* dst /*[(sh+1)/2][(sw+1)/2]*/);
+void vo_scharr_deriv(const uint8_t* src, int h, int w, short* deriv /*[h][w][2]*/);
+int vo_lk_levels(int h, int w, int win, int max_level);
+void vo_lk_track(const uint8_t* prev, const uint8_t* next, int h, int w, const float* pts, int count, int win,
+                 int max_level, int max_count, double epsilon, float* out_pts, uint8_t* status);
 
 #ifdef __cplusplus
 }

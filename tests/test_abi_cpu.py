@@ -64,6 +64,9 @@ def test_node_schema_sockets(pkg):
     assert [i.id for i in s.inputs] == ["frames", "frame_rate", "framing_mode", "transform_mode", "camera_lock",
                                         "strength", "smooth", "keep_fov", "padding_color"]
     assert [o.id for o in s.outputs] == ["frames_stabilized", "padding_mask", "meta"]
+    c = nodes.VideoStabilizerClassic.define_schema()   # classic.py:575-666: same sockets as Flow
+    assert c.node_id == "video_stabilizer_classic" and c.display_name == "Video Stabilizer Classic"
+    assert [i.id for i in c.inputs] == [i.id for i in s.inputs] and [o.id for o in c.outputs] == [o.id for o in s.outputs]
     s = nodes.VideoStabilizerMotionApply.define_schema()
     assert s.node_id == "video_stabilizer_motion_apply" and s.display_name == "Video Stabilizer Motion Apply"
     assert [i.id for i in s.inputs] == ["frames", "motion_meta", "framing_mode", "interpolation", "padding_color",
@@ -129,3 +132,42 @@ def test_oracle_dis_and_fit_recover_known_motion(oracle):
     assert mode == "similarity" and conf > 0.8 and resid < 0.5
     assert abs(m[0, 2] - tx) < 0.5 and abs(m[1, 2] - ty) < 0.5 and abs(m[0, 0] - 1) < 0.01
     assert oracle.dis_coarsest_scale(540, 960) == 5 and oracle.dis_coarsest_scale(480, 854) == 5
+
+
+def test_min_eigen_map_building_blocks(oracle):
+    """Oracle self-consistency of the Classic estimator restatement (oracle/vo_classic.c): pyrDown of a constant image is the
+    constant, Scharr of a ramp is the analytic slope, the eigenvalue map of a flat image is zero."""
+    flat = np.full((40, 60), 77, np.uint8)
+    assert np.all(oracle.pyr_down(flat) == 77) and oracle.pyr_down(flat).shape == (20, 30)
+    ramp = np.tile(np.arange(60, dtype=np.uint8) * 2, (40, 1))
+    d = oracle.scharr_deriv(ramp)
+    assert np.all(d[:, 1:-1, 0] == 2 * 2 * 16) and np.all(d[..., 1] == 0)
+    assert np.all(oracle.min_eigen_val(flat) == 0)
+    assert oracle.lk_levels(480, 854) == 3 and oracle.lk_levels(48, 64) == 0 and oracle.lk_levels(135, 240) == 2
+
+
+def test_oracle_classic_estimator_recovers_known_motion(oracle):
+    """GFTT -> LK -> fit on an analytic texture under a known similarity (no interpolation in the generator):
+    the restated Classic estimator (classic.py:69-160) recovers the motion -- independent of any OpenCV."""
+    from tests.test_dis_gpu import moving_clip
+
+    h, w = 240, 426
+    gray, params = moving_clip(2, h, w, seed=17)
+    feats = oracle.good_features(gray[0], **oracle.GFTT)
+    assert 100 < feats.shape[0] <= 400
+    d = feats[:, None, :] - feats[None, :, :]
+    dist2 = (d ** 2).sum(-1) + np.eye(len(feats)) * 1e9
+    assert dist2.min() >= 49.0                      # minDistance = 7
+    nxt, status = oracle.lk_track(gray[0], gray[1], feats, **oracle.LK)
+    assert status.mean() > 0.9
+    m, used, conf = oracle.classic_estimate_pair(gray[0], gray[1], "similarity")
+    assert used == "similarity" and conf > 0.8
+
+    def to_texture(pr):
+        tx, ty, th, sc = pr
+        c, sn = np.cos(th) / sc, np.sin(th) / sc
+        lin = np.array([[c, sn, 0], [-sn, c, 0], [0, 0, 1.0]])
+        return np.array([[1, 0, w / 2], [0, 1, h / 2], [0, 0, 1.0]]) @ lin @ np.array([[1, 0, -w / 2 - tx], [0, 1, -h / 2 - ty], [0, 0, 1.0]])
+
+    expect = np.linalg.inv(to_texture(params[1])) @ to_texture(params[0])
+    assert np.abs(m[:2, :2] - expect[:2, :2]).max() < 2e-3 and np.abs(m[:2, 2] - expect[:2, 2]).max() < 0.3
