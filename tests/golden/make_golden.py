@@ -196,6 +196,34 @@ def main() -> None:
 
     (OUT / "reference_helpers.json").write_text(json.dumps(jsonable(g)))
 
+    # ---- the node pipelines' paths that never reach a cv2 call: empty and single-frame clips -----------
+    # (flow.py:242-310, classic.py:189-250).  Full meta dicts of the reference for Flow and Classic.
+    from nodes import video_stabilizer_classic as vc  # noqa: E402
+    from nodes import video_stabilizer_flow as vf  # noqa: E402
+
+    small: dict = {"cases": []}
+    one = (np.arange(6 * 8 * 3, dtype=np.float32).reshape(1, 6, 8, 3) % 17) / 16.0
+    calls = [
+        ("single", one, ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)),
+        ("single", one, ("expand", "perspective", True, 0.3, 0.2, 1.0, (1, 2, 3), 0.0)),
+        ("single", {"frames": one, "fps": 24.0}, ("crop", "translation", False, 1.0, 0.0, 0.6, (255, 0, 16), -5.0)),
+        ("empty", None, ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)),
+        ("empty", None, ("expand", "perspective", True, 0.3, 0.2, 0.6, (1, 2, 3), 0.0)),
+    ]
+    for kind, value, args in calls:
+        if kind == "single":
+            ctx = su._normalize_video_input(value)
+        else:
+            base_ctx = su._normalize_video_input(one)
+            ctx = su.VideoContext([], base_ctx.adapter, 8, 6, 3, None, "sequence", {})
+        entry = {"kind": kind, "args": list(args), "fps_in_dict": value["fps"] if isinstance(value, dict) else None}
+        for name, mod in (("flow", vf), ("classic", vc)):
+            r = mod._stabilize_frames(ctx, *args)
+            entry[name] = {"meta": r.meta, "frames": np.asarray(r.frames), "masks": np.asarray(r.masks)}
+        small["cases"].append(entry)
+    small["single_frame"] = one
+    (OUT / "reference_small_paths.json").write_text(json.dumps(jsonable(small)))
+
     # larger shake clips used as Motion Apply inputs for configs C3/C5 (matrices only)
     for tag, (n, w, h) in {"c3_256x1080p": (256, 1920, 1080), "c5_64x4k": (64, 3840, 2160)}.items():
         blk = sn.generate_shake_motion_meta(recipe=sn.STYLES["handheld"], frame_count=n, width=w, height=h, fps=16.0,

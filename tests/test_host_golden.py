@@ -230,3 +230,31 @@ def test_input_errors_and_soft_paths(hm):
     assert c.frames[0].shape == (6, 8, 3) and c.channels == 3
     c = hm._normalize_video_input([np.ones((6, 8), np.float32)])
     assert c.frames[0].shape == (6, 8, 3) and c.channels == 3
+
+
+SMALL = json.loads((Path(__file__).parent / "golden" / "reference_small_paths.json").read_text())
+
+
+@pytest.mark.parametrize("estimator", ["flow", "classic"])
+def test_empty_and_single_frame_paths_match_reference(pkg, hm, estimator):
+    """flow.py:242-310 / classic.py:189-250: the paths of `_stabilize_frames` that never reach a pixel kernel
+    (no GPU needed).  The complete meta dict -- keys in order, values, types -- and the passthrough outputs
+    equal what the reference's own function returned (captured by tests/golden/make_golden.py)."""
+    from vstab_amd import flow_pipeline as fp
+
+    one = nd(SMALL["single_frame"])
+    for case in SMALL["cases"]:
+        args = list(case["args"])
+        args[6] = tuple(args[6])
+        if case["kind"] == "single":
+            value = {"frames": one, "fps": case["fps_in_dict"]} if case["fps_in_dict"] is not None else one
+            context = hm._normalize_video_input(value)
+        else:
+            base = hm._normalize_video_input(one)
+            context = hm.VideoContext([], base.adapter, 8, 6, 3, None, "sequence", {})
+        res = fp._stabilize_frames(context, *args, estimator=estimator)
+        want = case[estimator]
+        assert list(res.meta.keys()) == list(want["meta"].keys()), (case["kind"], args)
+        assert json.dumps(res.meta) == json.dumps(want["meta"]), (case["kind"], args)
+        assert np.array_equal(np.asarray(res.frames, np.float32).reshape(nd(want["frames"]).shape), nd(want["frames"]))
+        assert np.asarray(res.masks).shape == nd(want["masks"]).shape and not np.asarray(res.masks).any()
