@@ -23,7 +23,8 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import host_math as hm
-from .flow_pipeline import complete_meta, estimate_transitions, plan_stabilization, prepare_meta
+from .flow_pipeline import (complete_meta, estimate_transitions, estimate_transitions_classic, plan_stabilization,
+                            prepare_meta)
 
 
 
@@ -35,7 +36,8 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=None) -> np.ndarray:
-    """all_gather of equally padded row blocks; returns the concatenation of the valid rows in rank order."""
+    """all_gather of equally padded row blocks; returns the concatenation of the valid rows in rank order.
+    One flat receive buffer and one device->host copy (8 per-rank copies cost more than the collective itself)."""
     import torch
     import torch.distributed as dist
 
@@ -46,10 +48,14 @@ def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=No
     t = torch.from_numpy(padded)
     if device is not None:
         t = t.to(device)
-    bucket = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(bucket, t, group=group)
-    parts = [b.cpu().numpy()[: counts[r]] for r, b in enumerate(bucket)]
-    return np.concatenate(parts, axis=0)
+    flat = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(flat, t, group=group)
+    except (RuntimeError, NotImplementedError):   # backend without the flat variant
+        bucket = [flat[r] for r in range(world)]
+        dist.all_gather(bucket, t, group=group)
+    host = flat.cpu().numpy()
+    return np.concatenate([host[r, : counts[r]] for r in range(world)], axis=0)
 
 
 def transition_counts(total_frames: int, world: int) -> List[int]:
@@ -88,7 +94,8 @@ def collective_device(ctx=None):
 
 
 def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, transform_mode: str, camera_lock: bool,
-                      strength: float, smooth: float, keep_fov: float, padding_rgb, frame_rate: float, group=None):
+                      strength: float, smooth: float, keep_fov: float, padding_rgb, frame_rate: float, group=None,
+                      estimator: str = "flow"):
     """Sharded equivalent of `_stabilize_frames` (flow.py:213-640).
 
     local_frames: device tensor [n_local (+1 halo for rank > 0), H, W, 3] float32 -- this rank's frames
@@ -111,11 +118,12 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     working_size = hm._working_estimation_size(width, height)
     from . import native
 
-    local_records = (estimate_transitions(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
+    estimate = estimate_transitions if estimator == "flow" else estimate_transitions_classic
+    local_records = (estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
                      else np.zeros((0, 3), native.FIT_DTYPE))
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)
     plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
-                              keep_fov, padding_rgb, fps_effective, fps_requested)
+                              keep_fov, padding_rgb, fps_effective, fps_requested, estimator=estimator)
     if plan.bypass_meta is not None:
         raise NotImplementedError("crop bypass is not wired into the sharded path")
     own = local_frames[halo:]

@@ -23,7 +23,7 @@ def _clip():
     return np.ascontiguousarray(f)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, estimator):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -44,7 +44,8 @@ def _worker(rank, world, port, out_dir):
         start, end = vd.shard_range(n, world, rank)
         halo = 1 if rank > 0 else 0
         local = torch.from_numpy(frames[start - halo:end]).cuda()
-        dst, mask, meta = vd.stabilize_sharded(ctx, local, n, "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+        dst, mask, meta = vd.stabilize_sharded(ctx, local, n, "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
+                                               estimator=estimator)
         np.save(Path(out_dir) / f"dst_{rank}.npy", dst.cpu().numpy())
         np.save(Path(out_dir) / f"mask_{rank}.npy", mask.cpu().numpy())
         (Path(out_dir) / f"meta_{rank}.json").write_text(json.dumps(meta))
@@ -52,7 +53,8 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path):
+@pytest.mark.parametrize("estimator", ["flow", "classic"])
+def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path, estimator):
     import torch.multiprocessing as mp
 
     from vstab_amd import flow_pipeline as fp
@@ -61,9 +63,10 @@ def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), estimator), nprocs=2, join=True)
     frames = _clip()
-    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
+                               estimator=estimator)
     dst = np.concatenate([np.load(tmp_path / f"dst_{r}.npy") for r in range(2)])
     mask = np.concatenate([np.load(tmp_path / f"mask_{r}.npy") for r in range(2)])
     assert np.array_equal(dst, ref.frames) and np.array_equal(mask, ref.masks[..., 0])
