@@ -626,8 +626,15 @@ struct LevelArgs {
 };
 
 constexpr int SOR_HALO = 2 * SOR_ITERS;   // one pixel of dependency per half-sweep
-constexpr int SOR_NPT = 5;                // owned pixels per thread and colour (tile <= 10240 px at 1024 threads)
-constexpr int SOR_TILE_CAP = 2 * SOR_NPT * 1024;
+// Tuned on MI355X (profiles/r01_fused_tile_sweep.md): with 16 waves per CU a wave has 128 VGPRs; 4 or 5 owned
+// pixels per colour spill (the per-pixel LDS addresses are hoisted out of the sweep loop next to the
+// coefficients), and the spills cost more than the extra halo work of smaller tiles.
+#ifndef VSTAB_FUSED_T
+#define VSTAB_FUSED_T 1024
+#define VSTAB_SOR_NPT 3
+#endif
+constexpr int FUSED_T = VSTAB_FUSED_T;    // threads of the fused level kernel
+constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour (tile <= 2 * SOR_NPT * FUSED_T px)
 
 // One workgroup per frame pair runs densification, the whole variational refinement and the x2 upsample
 // to the next finer level in ONE launch.  The red-black SOR sweeps of a fixed-point iteration are
@@ -636,7 +643,7 @@ constexpr int SOR_TILE_CAP = 2 * SOR_NPT * 1024;
 // owned pixel sit in registers and never reach memory, all 10 half-sweeps run on-chip, and only the tile
 // interior is written back (double-buffered, because neighbouring tiles still need the old halo).
 // tempW of OpenCV (W + dW) is recomputed where needed instead of stored.
-__global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
+__global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
 {
     extern __shared__ float vr_lds[];
     const int pair = blockIdx.x;
@@ -663,6 +670,10 @@ __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
     FOR_PX(vr_deriv1_px(b, t, x, y, h, w))
     FOR_PX(vr_deriv2_px(b, t, x, y, h, w))
 
+    const float* __restrict__ pIx = b.Ix + base;   const float* __restrict__ pIy = b.Iy + base;
+    const float* __restrict__ pIz = b.Iz + base;   const float* __restrict__ pIxx = b.Ixx + base;
+    const float* __restrict__ pIxy = b.Ixy + base; const float* __restrict__ pIyy = b.Iyy + base;
+    const float* __restrict__ pIxz = b.Ixz + base; const float* __restrict__ pIyz = b.Iyz + base;
     float* lW = vr_lds;                    // smoothness weights
     float* lU = vr_lds + a.lds_plane;      // dU
     float* lV = vr_lds + 2 * a.lds_plane;  // dV
@@ -704,24 +715,28 @@ __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
             const int ncol = lh * half_lw;
             float c11[2][SOR_NPT], c12[2][SOR_NPT], c22[2][SOR_NPT], cb1[2][SOR_NPT], cb2[2][SOR_NPT];
             int cidx[2][SOR_NPT];
+            // Owned pixel j = 2*u + colour of this thread: k = threadIdx.x + u * FUSED_T = ly * half_lw + xh, advanced
+            // incrementally (one division per tile).  The loop is NOT unrolled: one pixel's ~60 temporaries are live at a
+            // time next to the persistent coefficient registers (an unrolled version interleaves the bodies and spills);
+            // the results are routed to their registers by compile-time-indexed selects.
+            const int step_rows = FUSED_T / half_lw, step_rem = FUSED_T - step_rows * half_lw;
+            int ly = (int)threadIdx.x / half_lw, xh = (int)threadIdx.x - ly * half_lw;
 #pragma unroll
-            for (int color = 0; color < 2; color++)
-#pragma unroll
-                for (int u = 0; u < SOR_NPT; u++) {
-                    const int k = threadIdx.x + u * 1024;
-                    cidx[color][u] = -1;
-                    if (k < ncol) {
-                        const int ly = k / half_lw;
+            for (int jj = 0; jj < 2 * SOR_NPT; jj++) cidx[jj & 1][jj >> 1] = -1;
+#pragma unroll 1
+            for (int j = 0; j < 2 * SOR_NPT; j++) {
+                const int color = j & 1;
+                const int k = threadIdx.x + (j >> 1) * FUSED_T;
+                if (k < ncol) {
                         const int gy = oy + ly;
-                        const int lx = 2 * (k - ly * half_lw) + ((gy + ox + color) & 1);
+                        const int lx = 2 * xh + ((gy + ox + color) & 1);
                         if (lx < lw) {
                             const int gx = ox + lx;
                             const int q = gy * w + gx;
                             const int li = (ly + 1) * pw + lx + 1;
-                            cidx[color][u] = li;
-                            const long long t = base + q;
-                            const float Ix = b.Ix[t], Iy = b.Iy[t], Iz = b.Iz[t], Ixx = b.Ixx[t], Ixy = b.Ixy[t], Iyy = b.Iyy[t],
-                                        Ixz = b.Ixz[t], Iyz = b.Iyz[t];
+                            const unsigned uq_ = (unsigned)q;   // uniform (SGPR) plane base + 32-bit lane offset
+                            const float Ix = pIx[uq_], Iy = pIy[uq_], Iz = pIz[uq_], Ixx = pIxx[uq_], Ixy = pIxy[uq_], Iyy = pIyy[uq_],
+                                        Ixz = pIxz[uq_], Iyz = pIyz[uq_];
                             const float du = lU[li], dv = lV[li];
                             float a11, a12, a22, B1, B2;
                             {
@@ -744,30 +759,34 @@ __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
                                 B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
                                 B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
                             }
-                            const bool red = ((gx + gy) & 1) == 0;
+                            // smoothness term, accumulated in OpenCV's red/black scatter order.  `color` IS the global
+                            // checkerboard parity (gx + gy) & 1 of the pixel, so the order is known at compile time.
                             const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
                             const float wq = lW[li], uq = U[q], vq = V[q];
-                            float own_hu = 0, own_hv = 0, left_hu = 0, left_hv = 0, wl = 0;
-                            if (has_r) { own_hu = wq * (U[q + 1] - uq); own_hv = wq * (V[q + 1] - vq); }
-                            if (has_l) { wl = lW[li - 1]; left_hu = wl * (uq - U[q - 1]); left_hv = wl * (vq - V[q - 1]); }
-                            float own_vu = 0, own_vv = 0, up_vu = 0, up_vv = 0, wu = 0;
-                            if (has_d) { own_vu = wq * (U[q + w] - uq); own_vv = wq * (V[q + w] - vq); }
-                            if (has_u) { wu = lW[li - pw]; up_vu = wu * (uq - U[q - w]); up_vv = wu * (vq - V[q - w]); }
-                            if (red) {
-                                if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-                                if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-                                if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-                                if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-                            } else {
-                                if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-                                if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-                                if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-                                if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-                            }
-                            c11[color][u] = a11; c12[color][u] = a12; c22[color][u] = a22; cb1[color][u] = B1; cb2[color][u] = B2;
+#define SM_RIGHT() if (has_r) { B1 += wq * (U[q + 1] - uq); a11 += wq; B2 += wq * (V[q + 1] - vq); a22 += wq; }
+#define SM_LEFT()  if (has_l) { const float wl = lW[li - 1]; B1 -= wl * (uq - U[q - 1]); a11 += wl; B2 -= wl * (vq - V[q - 1]); a22 += wl; }
+#define SM_DOWN()  if (has_d) { B1 += wq * (U[q + w] - uq); a11 += wq; B2 += wq * (V[q + w] - vq); a22 += wq; }
+#define SM_UP()    if (has_u) { const float wu = lW[li - pw]; B1 -= wu * (uq - U[q - w]); a11 += wu; B2 -= wu * (vq - V[q - w]); a22 += wu; }
+                            if (color == 0) { SM_RIGHT() SM_LEFT() SM_DOWN() SM_UP() }
+                            else            { SM_LEFT() SM_RIGHT() SM_UP() SM_DOWN() }
+#undef SM_RIGHT
+#undef SM_LEFT
+#undef SM_DOWN
+#undef SM_UP
+#pragma unroll
+                            for (int jj = 0; jj < 2 * SOR_NPT; jj++)
+                                if (jj == j) {
+                                    cidx[jj & 1][jj >> 1] = li;
+                                    c11[jj & 1][jj >> 1] = a11; c12[jj & 1][jj >> 1] = a12; c22[jj & 1][jj >> 1] = a22;
+                                    cb1[jj & 1][jj >> 1] = B1; cb2[jj & 1][jj >> 1] = B2;
+                                }
                         }
-                    }
                 }
+                if (color == 1) {
+                    xh += step_rem; ly += step_rows;
+                    if (xh >= half_lw) { xh -= half_lw; ly++; }
+                }
+            }
             // NOTE: a left/up neighbour outside the tile (but inside the image) reads the zero border here; that
             // only happens for halo pixels at the tile rim, whose values are never written back.
             // ---- stage 3: 2*SOR_ITERS half-sweeps entirely in LDS
@@ -788,6 +807,7 @@ __global__ __launch_bounds__(1024) void level_fused_kernel(LevelArgs a)
                             lU[li] = du;
                             lV[li] = dv;
                         }
+                        __builtin_amdgcn_sched_barrier(0);   // keep the owned pixels' updates apart (register pressure)
                     }
                 }
                 __syncthreads();
@@ -1012,7 +1032,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
                 return ((lw + 1) / 2) * lh;   // pixels of one colour
             };
             int padded = 0;
-            while (tile_px(tx, ty, padded) > SOR_NPT * 1024) {
+            while (tile_px(tx, ty, padded) > SOR_NPT * FUSED_T) {
                 if ((g.w + tx - 1) / tx >= (g.h + ty - 1) / ty) tx++; else ty++;
                 VSTAB_REQUIRE(tx <= 64 && ty <= 64, "vstab_dis_flow_batch: cannot tile a %dx%d level", g.w, g.h);
             }
@@ -1022,7 +1042,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         VSTAB_REQUIRE(vr_lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: SOR tile needs %zu B of LDS", vr_lds_bytes);
         if (vr_lds_bytes > 64 * 1024)
             VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
-        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(1024), vr_lds_bytes, st, la);
+        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(FUSED_T), vr_lds_bytes, st, la);
         VSTAB_HIP(hipGetLastError());
     }
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);
