@@ -263,7 +263,14 @@ __device__ __forceinline__ Bilin bilin_weights(int i, int j, float Ux, float Uy,
     return b;
 }
 
+#ifdef VSTAB_PIS_TRACE   // developer build: per-wave start/end stamps (tools/pis_residency.py)
+static long long* g_pis_dbg = nullptr;
+extern "C" void vstab_pis_dbg(long long* p) { g_pis_dbg = p; }
+#endif
 struct PisArgs {
+#ifdef VSTAB_PIS_TRACE
+    long long* dbg;
+#endif
     const uint8_t* I;      // [n][h][w]
     const uint8_t* Iext;   // [n][h+32][w+32]
     const short* Ix;       // [n][h][w]
@@ -294,8 +301,13 @@ __device__ __forceinline__ void wait_progress(volatile int* counter, int need)
     }
 }
 
+// Residency: the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) waves per SIMD, i.e. 8 only up to 80 SGPRs
+// (MI355X_MICROARCH.md, 'Residency'); unconstrained the compiler takes 100 and the 2 x P workgroups of a clip ran in
+// two rounds (tools/pis_residency.py: 254 of 510 started 0.8 ms late).  With the cap all are co-resident.  The gain
+// is small (5.95 -> 5.85 ms DIS per clip) because the kernel is VALU-bound either way: PMC SQ_ACTIVE_INST_VALU =
+// 7.3e8 wave-instructions x 4 cycles / 1024 SIMDs = 74 % of the launch.
 template <int PIS_ROW_WAVES>
-__global__ __launch_bounds__(256 * PIS_ROW_WAVES) void pis_kernel(PisArgs a)
+__global__ __launch_bounds__(256 * PIS_ROW_WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void pis_kernel(PisArgs a)
 {
     extern __shared__ unsigned char pis_lds[];
     const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
@@ -331,6 +343,9 @@ __global__ __launch_bounds__(256 * PIS_ROW_WAVES) void pis_kernel(PisArgs a)
     const float i_lo = DIS_BORDER - PSZ + 1.0f, i_hi = DIS_BORDER + h - 1.0f;
     const float j_lo = DIS_BORDER - PSZ + 1.0f, j_hi = DIS_BORDER + w - 1.0f;
     const int num_inner_iter = GD_ITERS / 2;
+#ifdef VSTAB_PIS_TRACE
+    const long long t_begin = wall_clock64();
+#endif
     const float nn = (float)(PSZ * PSZ);
     const int lane_off1 = r * w_ext + c;
 
@@ -424,6 +439,9 @@ __global__ __launch_bounds__(256 * PIS_ROW_WAVES) void pis_kernel(PisArgs a)
             }
         }
     }
+#ifdef VSTAB_PIS_TRACE
+    if (a.dbg && lane == 0) { long long* o = a.dbg + ((size_t)blockIdx.x * 16 + wave) * 2; o[0] = t_begin; o[1] = wall_clock64(); }
+#endif
     __syncthreads();
     // this block's stripes only
     const int blk_lo = min(half * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
@@ -999,6 +1017,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
         PisArgs pa{};
+#ifdef VSTAB_PIS_TRACE
+        pa.dbg = (i == FINEST) ? g_pis_dbg : nullptr;
+#endif
         pa.I = I[i]; pa.Iext = Iext[i]; pa.Ix = Ixs[i]; pa.Iy = Iys[i]; pa.tensor = tensor[i];
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
