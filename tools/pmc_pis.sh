@@ -7,7 +7,7 @@ OUT=/tmp/pmc_dis
 mkdir -p $OUT
 for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_IFETCH"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 > $OUT/$tag.log 2>&1 || echo "group failed: $grp"
+  timeout -k 10 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 > $OUT/$tag.log 2>&1 || echo "group failed: $grp"
 done
 python3 - <<PY
 import csv, glob, collections
