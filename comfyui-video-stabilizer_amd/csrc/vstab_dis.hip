@@ -627,7 +627,17 @@ __device__ __forceinline__ void upsample_px(const float* __restrict__ sU, const 
     dV[t] = (r0 * b0 + r1 * b1) * mul;
 }
 
+#ifdef VSTAB_FUSED_TRACE   // developer build: per-phase time of one workgroup (tools/fused_phases.py)
+static long long* g_dis_dbg = nullptr;
+extern "C" void vstab_dis_dbg(long long* p) { g_dis_dbg = p; }
+#define FUSED_MARK(i) do { if (prof_) { const long long now_ = wall_clock64(); a.dbg[i] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define FUSED_MARK(i)
+#endif
 struct LevelArgs {
+#ifdef VSTAB_FUSED_TRACE
+    long long* dbg;
+#endif
     const uint8_t* I;   // [n][h][w] pyramid level
     const float* Sx;    // [P][hs][ws]
     const float* Sy;
@@ -663,6 +673,11 @@ constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour 
 // tempW of OpenCV (W + dW) is recomputed where needed instead of stored.
 __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
 {
+#ifdef VSTAB_FUSED_TRACE
+    long long tprev_ = wall_clock64();
+    const bool prof_ = a.dbg && blockIdx.x == 7 && threadIdx.x == 0;
+#endif
+
     extern __shared__ float vr_lds[];
     const int pair = blockIdx.x;
     const int h = a.h, w = a.w;
@@ -684,9 +699,12 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
     }                                                                       \
     __syncthreads();
     FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
+    FUSED_MARK(0);
     FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
+    FUSED_MARK(1);
     FOR_PX(vr_deriv1_px(b, t, x, y, h, w))
     FOR_PX(vr_deriv2_px(b, t, x, y, h, w))
+    FUSED_MARK(2);
 
     const float* __restrict__ pIx = b.Ix + base;   const float* __restrict__ pIy = b.Iy + base;
     const float* __restrict__ pIz = b.Iz + base;   const float* __restrict__ pIxx = b.Ixx + base;
@@ -728,6 +746,7 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                 lW[k] = wv; lU[k] = du; lV[k] = dv;
             }
             __syncthreads();
+            FUSED_MARK(3);
             // ---- stage 2: linear system of the owned pixels -> registers
             const int half_lw = (lw + 1) >> 1;
             const int ncol = lh * half_lw;
@@ -807,6 +826,10 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
             }
             // NOTE: a left/up neighbour outside the tile (but inside the image) reads the zero border here; that
             // only happens for halo pixels at the tile rim, whose values are never written back.
+#ifdef VSTAB_FUSED_TRACE
+            __syncthreads();
+#endif
+            FUSED_MARK(4);
             // ---- stage 3: 2*SOR_ITERS half-sweeps entirely in LDS
             for (int s = 0; s < SOR_ITERS * 2; s++) {
 #pragma unroll
@@ -830,6 +853,7 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                 }
                 __syncthreads();
             }
+            FUSED_MARK(5);
             // ---- stage 4: write the tile interior of the new increment
             const int iw = ix1 - ix0, ih = iy1 - iy0;
             for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
@@ -840,6 +864,7 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                 dOut_v[gy * w + gx] = lV[li];
             }
             __syncthreads();
+            FUSED_MARK(6);
         }
         float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
         tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
@@ -851,6 +876,7 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
     }
     __syncthreads();
 #undef FOR_PX
+    FUSED_MARK(7);
     if (a.nextU != nullptr) {
         const int nn = a.nh * a.nw;
         const long long nbase = (long long)pair * nn;
@@ -859,6 +885,10 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
             upsample_px(a.U, a.V, a.nextU, a.nextV, base, nbase + q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
         }
     }
+#ifdef VSTAB_FUSED_TRACE
+    __syncthreads();
+    FUSED_MARK(8);
+#endif
 }
 
 // final resize of the finest flow to the working size (x 2^finest), evaluated on a strided grid
@@ -1037,6 +1067,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             hipLaunchKernelGGL(pis_kernel<1>, dim3((unsigned)P * 2), dim3(256), lds_bytes, st, pa);
         }
         LevelArgs la{};
+#ifdef VSTAB_FUSED_TRACE
+        la.dbg = g_dis_dbg ? g_dis_dbg + 16 * i : nullptr;
+#endif
         la.I = I[i]; la.Sx = Sx; la.Sy = Sy; la.U = Ul[i]; la.V = Vl[i]; la.vb = vb;
         la.P = P; la.h = g.h; la.w = g.w; la.ws = g.ws; la.hs = g.hs;
         la.alpha2 = alpha2; la.delta2 = delta2; la.gamma2 = gamma2; la.zeta2 = zeta2; la.eps2 = eps2; la.omega = omega;
