@@ -89,6 +89,18 @@ EventPair* vstab_timer_slot(vstab_ctx* ctx, const char* kind)
     return &it->second;
 }
 
+int vstab_timer_fold(EventPair* ev)
+{
+    if (!ev->pending) return 0;
+    float ms = 0.f;
+    VSTAB_HIP(hipEventSynchronize(ev->stop));
+    VSTAB_HIP(hipEventElapsedTime(&ms, ev->start, ev->stop));
+    ev->total_ms += ms;
+    ev->launches += 1;
+    ev->pending = false;
+    return 0;
+}
+
 extern "C" {
 
 int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
@@ -149,6 +161,7 @@ int vstab_set_timing(vstab_ctx* ctx, int enabled)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_set_timing: ctx is NULL");
     ctx->timing = enabled != 0;
+    for (auto& kv : ctx->timers) { kv.second.pending = false; kv.second.total_ms = 0.0; kv.second.launches = 0; }
     return 0;
 }
 
@@ -156,9 +169,21 @@ int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out)
 {
     VSTAB_REQUIRE(ctx != nullptr && kind != nullptr && ms_out != nullptr, "vstab_last_kernel_ms: NULL argument");
     auto it = ctx->timers.find(kind);
-    VSTAB_REQUIRE(it != ctx->timers.end() && it->second.pending, "vstab_last_kernel_ms: no timing recorded for '%s'", kind);
+    VSTAB_REQUIRE(it != ctx->timers.end() && it->second.start != nullptr && (it->second.pending || it->second.launches > 0),
+                  "vstab_last_kernel_ms: no timing recorded for '%s'", kind);
     VSTAB_HIP(hipEventSynchronize(it->second.stop));
     VSTAB_HIP(hipEventElapsedTime(ms_out, it->second.start, it->second.stop));
+    return 0;
+}
+
+int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, int* launches)
+{
+    VSTAB_REQUIRE(ctx != nullptr && kind != nullptr && total_ms != nullptr && launches != nullptr, "vstab_kernel_ms_stats: NULL argument");
+    auto it = ctx->timers.find(kind);
+    VSTAB_REQUIRE(it != ctx->timers.end(), "vstab_kernel_ms_stats: no timing recorded for '%s'", kind);
+    if (int rc = vstab_timer_fold(&it->second)) return rc;
+    *total_ms = it->second.total_ms;
+    *launches = it->second.launches;
     return 0;
 }
 

@@ -38,7 +38,14 @@ struct ScratchBuf {
     void release();
 };
 
-struct EventPair { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; };
+struct EventPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool pending = false;        // a start/stop pair has been recorded and not yet folded into the totals
+    double total_ms = 0.0;       // folded launches since vstab_set_timing(ctx, 1)
+    int launches = 0;
+};
+// Folds a finished, still pending measurement into the totals (blocks until the stop event has passed).
+int vstab_timer_fold(EventPair* ev);
 
 struct vstab_ctx {
     int device = 0;
@@ -66,6 +73,9 @@ struct KernelTimer {
     KernelTimer(vstab_ctx* c, const char* k) : ctx(c) {
         if (ctx->timing) {
             ev = vstab_timer_slot(ctx, k);
+            // the previous launch of this kind finished long ago (every pipeline pass synchronises with the host
+            // between two launches of the same kind), so folding it costs no wait
+            if (ev && ev->pending) (void)vstab_timer_fold(ev);
             if (ev) (void)hipEventRecord(ev->start, ctx->stream);
         }
     }

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "vstab_synchronize": (C.c_int, [C.c_void_p]),
     "vstab_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_last_kernel_ms": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]),
+    "vstab_kernel_ms_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "vstab_warp_batch": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -212,6 +213,12 @@ class Context:
         out = C.c_float()
         _check(self.lib.vstab_last_kernel_ms(self.handle, kind.encode(), C.byref(out)), "vstab_last_kernel_ms")
         return float(out.value)
+
+    def kernel_ms_stats(self, kind: str):
+        """(total ms, launches) of all calls of `kind` since set_timing(True)."""
+        total, launches = C.c_double(), C.c_int()
+        _check(self.lib.vstab_kernel_ms_stats(self.handle, kind.encode(), C.byref(total), C.byref(launches)), "vstab_kernel_ms_stats")
+        return float(total.value), int(launches.value)
 
     # ------------------------------------------------------------------ helpers
     def _as_device_frames(self, frames):

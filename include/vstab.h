@@ -52,11 +52,15 @@ int vstab_destroy(vstab_ctx* ctx);
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
 int vstab_set_stream(vstab_ctx* ctx, void* hip_stream);
 int vstab_synchronize(vstab_ctx* ctx);
-/* seconds the stream spent between the library's internal start/stop events of the
- * most recent call of the named kind ("warp","warp_blur","gray","dis","fit");
- * requires vstab_set_timing(ctx,1).  Used by bench.py for the roofline line. */
+/* Kernel timing with HIP events recorded on the call's own stream, per kind of call ("warp", "warp_blur",
+ * "gray", "dis", "fit", "gftt", "lk").  vstab_set_timing(ctx, 1) enables it and clears the totals.
+ * vstab_last_kernel_ms: milliseconds of the most recent call of that kind (waits for it to finish).
+ * vstab_kernel_ms_stats: sum and number of all calls of that kind since timing was enabled -- no
+ * synchronisation is needed inside a timed loop, bench.py reads the totals after its closing fence
+ * for the roofline line. */
 int vstab_set_timing(vstab_ctx* ctx, int enabled);
 int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out);
+int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, int* launches);
 
 /* ---- F13 / A3: per-frame warp with padding mask ---------------------------
  * Replaces the loop at nodes/video_stabilizer_flow.py:560-588 and
