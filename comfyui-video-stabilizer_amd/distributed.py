@@ -127,7 +127,7 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     if plan.bypass_meta is not None:
         raise NotImplementedError("crop bypass is not wired into the sharded path")
     own = local_frames[halo:]
-    mats = np.stack(plan.final_matrices[start:end]).astype(np.float32)
+    mats = np.ascontiguousarray(plan.final_matrices[start:end], dtype=np.float32)
     dst, mask, counts = ctx.warp_batch(own, mats, plan.output_size, interp="bilinear", border=hm.border_value(padding_rgb),
                                        want_mask=True, want_count=True)
     meta = prepare_meta(plan)  # host JSON work overlaps this rank's warp kernel

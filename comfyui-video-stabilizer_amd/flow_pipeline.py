@@ -63,15 +63,13 @@ def _attach_motion_meta(meta: Dict[str, Any], fps: float, estimator: str = "flow
 
 
 def _replay_progress(pbar, done: int, count: int, total: int, stride: int = 10) -> int:
-    """Emit the update_absolute sequence the reference's per-item loop produces (flow.py:347-351, 589-593)."""
-    pending = 0
-    for k in range(count):
-        pending += 1
-        if pending >= stride or k == count - 1:
-            done += pending
-            pbar.update_absolute(done, total)
-            pending = 0
-    return done
+    """Emit the update_absolute sequence the reference's per-item loop produces (flow.py:347-351, 589-593):
+    one call per `stride` finished items and one for the remainder."""
+    for upto in range(stride, count + 1, stride):
+        pbar.update_absolute(done + upto, total)
+    if count % stride:
+        pbar.update_absolute(done + count, total)
+    return done + count
 
 
 _MODE_INDEX = {"translation": 0, "similarity": 1, "perspective": 2}
@@ -163,7 +161,7 @@ class FlowPlan:
     """Everything the warp stage and the meta need, derived on the host from the per-pair fits
     (replicated on every rank in multi-GPU runs: deterministic fp64 / integer logic only)."""
 
-    final_matrices: List[np.ndarray]
+    final_matrices: np.ndarray         # float32 [N,3,3] (source -> output), stacked: indexable per frame, no list copies
     output_size: Tuple[int, int]
     meta_head: Dict[str, Any]          # keys of flow.py:598-611 that do not depend on the warp
     framing_meta: Dict[str, Any]
@@ -242,7 +240,8 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
                 "padding_fraction_mean": 0.0,
                 "padding_fraction_max": 0.0,
             }
-            return FlowPlan([], size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta, estimator=estimator)
+            return FlowPlan(np.zeros((0, 3, 3), np.float32), size, {}, {}, {}, framing_mode, size, fps_effective, bypass_meta=meta,
+                            estimator=estimator)
         # flow.py:431-470: keep_fov solver, then the padding-free refinement
         from .crop_solver import solve_crop
 
@@ -263,7 +262,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         "min_content_ratio": hm._min_content_ratio(mins, maxs, width, height),
     }
     if framing_mode == "crop":  # flow.py:485-499
-        final_matrices = [np.asarray(m, dtype=np.float32) for m in crop_solution["final_matrices"]]
+        final_matrices = np.stack([np.asarray(m, dtype=np.float32) for m in crop_solution["final_matrices"]])
         framing_meta.update({
             "keep_fov_status": crop_solution["status"],
             "keep_fov_effective": crop_solution["keep_fov_effective"],
@@ -283,7 +282,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         off_x = width * 0.5 - (x0 + x1) * 0.5
         off_y = height * 0.5 - (y0 + y1) * 0.5
         shift = np.array([[1.0, 0.0, off_x], [0.0, 1.0, off_y], [0.0, 0.0, 1.0]], dtype=np.float32)
-        final_matrices = list(np.matmul(shift, apply_matrices))
+        final_matrices = np.matmul(shift, apply_matrices)
         framing_meta.update({
             "safe_region_origin": [x0, y0],
             "safe_region_size": [inter_w, inter_h],
@@ -292,7 +291,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         })
     elif framing_mode == "expand":  # flow.py:530-533
         shift, output_size = hm._prepare_expand_transform(mins, maxs)
-        final_matrices = list(np.matmul(shift, apply_matrices))
+        final_matrices = np.matmul(shift, apply_matrices)
         framing_meta["expanded_size"] = list(output_size)
     else:
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop', 'crop_and_pad', or 'expand'.")
@@ -332,7 +331,7 @@ def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
     stabilization_warp + motion_meta).  Called while the warp kernel is still running."""
     h = plan.meta_head
     em = plan.estimated_motion
-    final_stack = np.asarray(plan.final_matrices, dtype=np.float32).reshape(-1, 3, 3)
+    final_stack = plan.final_matrices
     meta = {
         "frames": h["frames"],
         "transform_mode_requested": h["transform_mode_requested"],
@@ -482,7 +481,7 @@ def _stabilize_frames(
 
     # ---- warp (F13) ------------------------------------------------------------
     dst, mask, counts = ctx.warp_batch(
-        device_frames, np.stack(plan.final_matrices).astype(np.float32), plan.output_size, interp="bilinear",
+        device_frames, plan.final_matrices, plan.output_size, interp="bilinear",
         border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
     meta = prepare_meta(plan)  # host JSON work overlaps the warp kernel
     meta = complete_meta(meta, plan, counts.cpu().numpy())

@@ -33,7 +33,7 @@ def step(tm):
     records = np.concatenate(reps)[: total - 1]
     plan = fp.plan_stabilization(ctx, records, size, total, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0, 16.0)
     t2 = time.perf_counter()
-    mats = np.stack(plan.final_matrices[:n]).astype(np.float32)
+    mats = np.ascontiguousarray(plan.final_matrices[:n], dtype=np.float32)
     dst, mask, counts = ctx.warp_batch(frames, mats, plan.output_size, interp="bilinear", border=hm.border_value((127, 127, 127)),
                                        want_mask=True, want_count=True)
     t3 = time.perf_counter()
