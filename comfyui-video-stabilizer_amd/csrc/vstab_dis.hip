@@ -238,8 +238,11 @@ __device__ __forceinline__ float wave_sum(float v)
     v += dpp_fetch<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
     v += dpp_fetch<0x141, 0xf>(v);   // row_half_mirror
     v += dpp_fetch<0x140, 0xf>(v);   // row_mirror
-    v += dpp_fetch<0x142, 0xa>(v);   // row_bcast15 into rows 1,3
-    v += dpp_fetch<0x143, 0xc>(v);   // row_bcast31 into rows 2,3
+    // row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3 as single DPP adds that leave the other rows untouched
+    // (the builtin form needs a zero-filled temporary and a separate add: 8 of the ~105 instructions of a
+    // gradient-descent step, and this kernel is VALU-bound).  Only lane 63, which both steps write, is read below.
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 

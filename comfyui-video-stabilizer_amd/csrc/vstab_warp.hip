@@ -284,9 +284,11 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
                     double Wq, Wn;
                     if (affine) { Wq = xf->wq; Wn = xf->wn; }
                     else {
+                        // one fp64 division serves both: 32/W == 32 * (1/W) bit for bit (scaling a correctly rounded
+                        // quotient by a power of two is exact)
                         const double W = W0 + m6 * dx1;
-                        Wq = (W != 0.0) ? 32.0 / W : 0.0;
                         Wn = (W != 0.0) ? 1.0 / W : 0.0;
+                        Wq = 32.0 * Wn;
                     }
                     if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
                         const float w = x * mf[6] + y * mf[7] + mf[8];

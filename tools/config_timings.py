@@ -7,6 +7,9 @@ import __graft_entry__ as graft
 graft.load_package()
 import bench
 from vstab_amd import apply_pipeline as ap, flow_pipeline as fp, host_math as hm, native
+import os
+if os.environ.get("VSTAB_LIB"):   # A/B runs of two builds
+    native.LIB_PATH = Path(os.environ["VSTAB_LIB"]).resolve()
 
 ap_ = argparse.ArgumentParser(); ap_.add_argument("--config", default="c3"); ap_.add_argument("--reps", type=int, default=3)
 args = ap_.parse_args()
