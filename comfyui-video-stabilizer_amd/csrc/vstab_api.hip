@@ -1,5 +1,6 @@
 // vstab_api.hip -- context, error reporting and staging helpers of libvstab.so.
 #include "vstab_internal.h"
+#include <cmath>
 #include <cstdarg>
 
 static thread_local char g_err[1024] = "";
@@ -184,6 +185,26 @@ int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, in
     if (int rc = vstab_timer_fold(&it->second)) return rc;
     *total_ms = it->second.total_ms;
     *launches = it->second.launches;
+    return 0;
+}
+
+// Element-wise libm calls for the host-side parameter maps (stabilizer_utils.py:300-358 uses Python's math.*,
+// i.e. this process's libm): the same functions without 6 Python-level calls per frame.
+int vstab_host_math(int op, const double* a, const double* b, int n, double* out)
+{
+    VSTAB_REQUIRE(a != nullptr && out != nullptr && n >= 0, "vstab_host_math: bad argument");
+    VSTAB_REQUIRE(op >= VSTAB_HOST_SQRT && op <= VSTAB_HOST_SIN, "vstab_host_math: unknown op %d", op);
+    VSTAB_REQUIRE(op != VSTAB_HOST_ATAN2 || b != nullptr, "vstab_host_math: atan2 needs two inputs");
+    for (int i = 0; i < n; i++) {
+        switch (op) {
+        case VSTAB_HOST_SQRT: out[i] = std::sqrt(a[i]); break;
+        case VSTAB_HOST_ATAN2: out[i] = std::atan2(a[i], b[i]); break;
+        case VSTAB_HOST_LOG: out[i] = std::log(a[i]); break;
+        case VSTAB_HOST_EXP: out[i] = std::exp(a[i]); break;
+        case VSTAB_HOST_COS: out[i] = std::cos(a[i]); break;
+        default: out[i] = std::sin(a[i]); break;
+        }
+    }
     return 0;
 }
 

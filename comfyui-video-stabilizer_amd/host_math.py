@@ -273,13 +273,25 @@ def _params_to_matrix(params: np.ndarray, base_mode: str) -> np.ndarray:
     return np.array([[p[0] + 1.0, p[1], p[2]], [p[3], p[4] + 1.0, p[5]], [p[6], p[7], 1.0]], dtype=np.float32)
 
 
-# element-wise libm calls (exactly what the per-item helpers use) without a Python-level loop
-_ATAN2 = np.frompyfunc(math.atan2, 2, 1)
-_LOG = np.frompyfunc(math.log, 1, 1)
-_SQRT = np.frompyfunc(math.sqrt, 1, 1)
-_EXP = np.frompyfunc(math.exp, 1, 1)
-_COS = np.frompyfunc(math.cos, 1, 1)
-_SIN = np.frompyfunc(math.sin, 1, 1)
+# element-wise libm calls (exactly what the per-item helpers use) for whole clips: libvstab's host helper runs the
+# process's libm over the array; without the library (host-only use) the same functions are reached through
+# np.frompyfunc(math.*) -- both give the bits of the per-item form
+def _libm(name: str, a, b=None) -> np.ndarray:
+    try:
+        from . import native
+
+        return native.host_math(name, a, b)
+    except (ImportError, OSError, RuntimeError):
+        fn = np.frompyfunc(getattr(math, name), 1 if b is None else 2, 1)
+        return (fn(a) if b is None else fn(a, b)).astype(np.float64)
+
+
+def _SQRT(a): return _libm("sqrt", a)
+def _ATAN2(a, b): return _libm("atan2", a, b)
+def _LOG(a): return _libm("log", a)
+def _EXP(a): return _libm("exp", a)
+def _COS(a): return _libm("cos", a)
+def _SIN(a): return _libm("sin", a)
 
 
 def matrices_to_params(stack: np.ndarray, base_mode: str) -> np.ndarray:

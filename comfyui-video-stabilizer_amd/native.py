@@ -127,6 +127,7 @@ _SIGNATURES = {
                   C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_points_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_host_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_crop_analysis": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_trajectory": (
@@ -159,6 +160,19 @@ def load_library():
             raise VstabError(f"libvstab ABI version {lib.vstab_abi_version()} != 1")
         _lib = lib
     return _lib
+
+
+HOST_OPS = {"sqrt": 0, "atan2": 1, "log": 2, "exp": 3, "cos": 4, "sin": 5}
+
+
+def host_math(op: str, a, b=None) -> np.ndarray:
+    """Element-wise libm call over fp64 arrays (vstab_host_math): the functions Python's math module binds."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    rc = load_library().vstab_host_math(HOST_OPS[op], a.ctypes.data, bb.ctypes.data if bb is not None else None, a.size, out.ctypes.data)
+    _check(rc, "vstab_host_math")
+    return out
 
 
 def _check(rc: int, what: str) -> None:

@@ -200,6 +200,13 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
                      double fps, double strength, int camera_lock, double* path,
                      double* target);
 
+/* ---- F6 / F9 host helper: element-wise libm over fp64 arrays (host pointers, no GPU involved) ----
+ * nodes/stabilizer_utils.py:300-358 (_matrix_to_params / _params_to_matrix) call math.sqrt/atan2/log and
+ * math.exp/cos/sin per frame; this runs the same libm functions over a whole clip in one call.
+ * b is only read by VSTAB_HOST_ATAN2 (out = atan2(a, b)). */
+enum { VSTAB_HOST_SQRT = 0, VSTAB_HOST_ATAN2 = 1, VSTAB_HOST_LOG = 2, VSTAB_HOST_EXP = 3, VSTAB_HOST_COS = 4, VSTAB_HOST_SIN = 5 };
+int vstab_host_math(int op, const double* a, const double* b, int n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,3 +171,21 @@ def test_oracle_classic_estimator_recovers_known_motion(oracle):
 
     expect = np.linalg.inv(to_texture(params[1])) @ to_texture(params[0])
     assert np.abs(m[:2, :2] - expect[:2, :2]).max() < 2e-3 and np.abs(m[:2, 2] - expect[:2, 2]).max() < 0.3
+
+
+def test_host_math_is_pythons_libm(pkg):
+    """vstab_host_math (no GPU involved) must return the bits of math.sqrt/atan2/log/exp/cos/sin -- the functions
+    the reference's _matrix_to_params / _params_to_matrix call per frame (stabilizer_utils.py:300-358)."""
+    import math
+
+    from vstab_amd import native
+
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.normal(0, 3, 4000), [0.0, -0.0, 1.0, 1e-300, 1e300, np.pi, -np.pi / 2]])
+    b = np.concatenate([rng.normal(0, 3, 4000), [0.0, 0.0, -1.0, 1e300, 1e-300, -0.0, 0.0]])
+    cases = {"sqrt": (np.abs(a),), "atan2": (a, b), "log": (np.abs(a) + 1e-12,), "exp": (np.clip(a, -700, 700),),
+             "cos": (a * 1e3,), "sin": (a * 1e3,)}
+    for name, args in cases.items():
+        got = native.host_math(name, *args)
+        want = np.array([getattr(math, name)(*[float(x[i]) for x in args]) for i in range(a.size)])
+        assert np.array_equal(got, want, equal_nan=True), name
