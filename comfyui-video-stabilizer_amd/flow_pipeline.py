@@ -85,6 +85,10 @@ def select_transitions(fit_records, requested_mode: str):
     pairs = table.shape[0]
     usable = (table["computed"] != 0) & (table["accepted"] != 0)   # [P,3], mode index 0..2
     active = _MODE_INDEX[requested_mode]
+    if pairs and usable[:, active].all():   # the common case: the requested model was accepted for every pair
+        rows = table[:, active]
+        return (rows["matrix"].reshape(pairs, 3, 3).astype(np.float32), [requested_mode] * pairs, rows["confidence"].tolist(),
+                rows["residual"].tolist(), requested_mode)
     chosen = np.empty(pairs, dtype=np.int64)
     p = 0
     while p < pairs:

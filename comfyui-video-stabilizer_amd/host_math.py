@@ -360,9 +360,13 @@ def bounding_boxes_batched(stack: np.ndarray, width: int, height: int):
     """`_compute_bounding_boxes` for a stacked [N,3,3] array (one batched matmul)."""
     corners = np.array([[0.0, 0.0, 1.0], [width, 0.0, 1.0], [0.0, height, 1.0], [width, height, 1.0]], dtype=np.float64).T
     pts = np.matmul(stack, corners)
-    pts = pts / pts[:, 2:3, :]
-    mins = np.stack([pts[:, 0].min(axis=1), pts[:, 1].min(axis=1)], axis=1)
-    maxs = np.stack([pts[:, 0].max(axis=1), pts[:, 1].max(axis=1)], axis=1)
+    wq = pts[:, 2, :]
+    xs, ys = pts[:, 0, :] / wq, pts[:, 1, :] / wq          # [N,4] each, same quotients as `pts /= pts[2]`
+    # min / max of four values: pairwise ufuncs on contiguous columns instead of four strided axis reductions
+    x0, x1, x2, x3 = np.ascontiguousarray(xs.T)
+    y0, y1, y2, y3 = np.ascontiguousarray(ys.T)
+    mins = np.stack([np.minimum(np.minimum(x0, x1), np.minimum(x2, x3)), np.minimum(np.minimum(y0, y1), np.minimum(y2, y3))], axis=1)
+    maxs = np.stack([np.maximum(np.maximum(x0, x1), np.maximum(x2, x3)), np.maximum(np.maximum(y0, y1), np.maximum(y2, y3))], axis=1)
     return mins, maxs
 
 
