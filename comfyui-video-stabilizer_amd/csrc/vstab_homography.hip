@@ -57,10 +57,21 @@ __device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, 
 
 // JacobiImpl_ of OpenCV (core/src/lapack.cpp) for a symmetric n x n fp64 matrix; eigenvalues sorted descending,
 // eigenvectors are the rows of V.
-__device__ void jacobi_eigen(double* A, int n, double* W, double* V)
+// Workspace of one eigen-solve / one 8x8 elimination.  It lives in LDS: the solvers index their matrices with
+// run-time pivots, which would otherwise put them in scratch memory (a phase profile showed the 16 concurrent
+// 4-point solves taking 1.1 ms and the single-lane refit 0.4 ms that way).  181 doubles per slot: consecutive
+// slots start 10 banks apart, so the lanes of a batch do not collide on equal indices.
+struct JacWs {
+    double A[81];
+    double V[81];
+    double W[9];
+    int indR[9], indC[9];
+    double pad;
+};
+
+__device__ void jacobi_eigen(double* A, int n, double* W, double* V, int* indR, int* indC)
 {
     const double eps = 2.220446049250313e-16;
-    int indR[9], indC[9];
     int i, j, k, m;
     double mv;
     for (i = 0; i < n; i++) {
@@ -145,14 +156,14 @@ __device__ void jacobi_eigen(double* A, int n, double* W, double* V)
 }
 
 // H from the normalisation parameters and LtL (HomographyEstimatorCallback::runKernel after the accumulation)
-__device__ void homography_from_ltl(double* LtL, double cmx, double cmy, double cMx, double cMy, double smx, double smy,
+__device__ void homography_from_ltl(JacWs& ws, double cmx, double cmy, double cMx, double cMy, double smx, double smy,
                                     double sMx, double sMy, double* H)
 {
-    double W[9], V[81];
+    double* LtL = ws.A;   // upper triangle filled by the caller
     for (int j = 0; j < 9; j++)
         for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi_eigen(LtL, 9, W, V);
-    const double* H0 = V + 72;
+    jacobi_eigen(LtL, 9, ws.W, ws.V, ws.indR, ws.indC);
+    const double* H0 = ws.V + 72;
     const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
     const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
     double T[9], R[9];
@@ -172,9 +183,9 @@ __device__ void homography_from_ltl(double* LtL, double cmx, double cmy, double 
     for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
 }
 
-__device__ bool homography_4pt(const float* M, const float* m, double* H)
+__device__ bool homography_4pt(JacWs& ws, const float* M, const float* m, double* H)
 {
-    double LtL[81];
+    double* LtL = ws.A;
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
     const int count = 4;
     for (int i = 0; i < count; i++) { cmx += m[i * 2]; cmy += m[i * 2 + 1]; cMx += M[i * 2]; cMy += M[i * 2 + 1]; }
@@ -195,7 +206,7 @@ __device__ bool homography_4pt(const float* M, const float* m, double* H)
         for (int j = 0; j < 9; j++)
             for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
     }
-    homography_from_ltl(LtL, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
+    homography_from_ltl(ws, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
     return true;
 }
 
@@ -239,9 +250,8 @@ __device__ __forceinline__ T block_sum(T v, T* scratch)
 }
 
 // solve the symmetric n x n system A x = b (n <= 8) by Gaussian elimination with partial pivoting
-__device__ bool solve_sym(const double* A_in, const double* b, int n, double* x)
+__device__ bool solve_sym(double (*A)[9] /* 8 rows of LDS workspace */, const double* A_in, const double* b, int n, double* x)
 {
-    double A[8][9];
     for (int r = 0; r < n; r++) {
         for (int c = 0; c < n; c++) A[r][c] = A_in[r * n + c];
         A[r][n] = b[r];
@@ -338,6 +348,8 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
     __shared__ double s_lm[8];   // 0 lambda, 1 lc, 2 S, 3 flag
     __shared__ int s_ctl[5];     // 0 done, 1 niters, 2 iter, 3 maxGood, 4 subset_failed
     __shared__ Rng s_rng;
+    __shared__ JacWs s_ws[HBATCH];
+    double (*elim)[9] = reinterpret_cast<double (*)[9]>(s_ws[1].A);   // 8x9 elimination tableau of the LM steps (lane 0 only)
 
     const int pair = blockIdx.x, tid = threadIdx.x;
     const bool points = a.gw == 0;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
                 float ms1[8], ms2[8];
                 for (int i = 0; i < 4; i++) load_point(F, a.gw, a.step, vmap[s_idx[tid][i]], ms1[i * 2], ms1[i * 2 + 1], ms2[i * 2], ms2[i * 2 + 1]);
                 double H[9];
-                if (homography_4pt(ms1, ms2, H)) {
+                if (homography_4pt(s_ws[tid], ms1, ms2, H)) {
                     for (int k = 0; k < 9; k++) s_model[tid][k] = H[k];
                     for (int k = 0; k < 8; k++) s_modelf[tid][k] = (float)H[k];
                     s_ok[tid] = 1;
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             for (int j = 0; j < 9; j++)
                 for (int q = j; q < 9; q++) acc[idx++] += Lx[j] * Lx[q] + Ly[j] * Ly[q];
         }
-        __shared__ double s_LtL[81];
+        double* s_LtL = s_ws[0].A;   // the refit reuses slot 0 (the batch solves are finished)
         int idx = 0;
         for (int j = 0; j < 9; j++)
             for (int q = j; q < 9; q++) {
@@ -500,9 +512,8 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             }
         __syncthreads();
         if (tid == 0) {
-            double L[81], H[9];
-            for (int i = 0; i < 81; i++) L[i] = s_LtL[i];
-            homography_from_ltl(L, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
+            double H[9];
+            homography_from_ltl(s_ws[0], cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
             for (int i = 0; i < 9; i++) s_best[i] = H[i];
         }
         __syncthreads();
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             for (int i = 0; i < 64; i++) Ap[i] = s_A[i];
             for (int i = 0; i < 8; i++) Ap[i * 8 + i] += s_lm[0] * s_D[i];
             double d[8];
-            if (!solve_sym(Ap, s_v, 8, d)) for (int i = 0; i < 8; i++) d[i] = 0;
+            if (!solve_sym(elim, Ap, s_v, 8, d)) for (int i = 0; i < 8; i++) d[i] = 0;
             for (int i = 0; i < 8; i++) { s_d[i] = d[i]; s_x[i] = x[i] - d[i]; }
         }
         __syncthreads();
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
                     for (int c = 0; c < 8; c++) {   // diagonal of A^-1, column by column
                         double e[8], col[8];
                         for (int i = 0; i < 8; i++) e[i] = (i == c);
-                        if (solve_sym(s_A, e, 8, col)) maxval = fmax(maxval, fabs(col[c]));
+                        if (solve_sym(elim, s_A, e, 8, col)) maxval = fmax(maxval, fabs(col[c]));
                     }
                     lambda = lc = 1. / maxval;
                     nu *= 0.5;
