@@ -84,10 +84,17 @@ except ImportError:
         slider = "slider"
         number = "number"
 
+    class _ControlAfterGenerate:
+        fixed = "fixed"
+        increment = "increment"
+        decrement = "decrement"
+        randomize = "randomize"
+
     class _IO:
         Schema = _Schema
         NodeOutput = _NodeOutput
         NumberDisplay = _NumberDisplay
+        ControlAfterGenerate = _ControlAfterGenerate
         Image = _socket_type("Image")
         Mask = _socket_type("Mask")
         Float = _socket_type("Float")

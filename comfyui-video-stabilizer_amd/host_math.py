@@ -226,6 +226,14 @@ def _working_estimation_size(width: int, height: int, max_side: int = DEFAULT_ES
     return sw, sh
 
 
+def _resolve_fps(context, frame_rate, default: float = 16.0) -> float:
+    """First usable value of: fps carried by the input, the widget, the default (stabilizer_utils.py:75-79)."""
+    for candidate in (context.fps, frame_rate, default):
+        if isinstance(candidate, (int, float)) and np.isfinite(candidate) and candidate > 0.0:
+            return float(candidate)
+    return float(default)
+
+
 def _rescale_transform_to_full(matrix: np.ndarray, source_size, working_size) -> np.ndarray:
     """S^-1 @ M @ S in fp64, stored as float32 (stabilizer_utils.py:279-297)."""
     sx = working_size[0] / float(source_size[0])

@@ -16,6 +16,7 @@ from .apply_pipeline import apply_motion
 from .meta_v2 import resolve_motion_meta
 from .comfy_compat import ComfyExtension, ProgressBar, io
 from .flow_pipeline import _stabilize_frames
+from .shake_generator import STYLES, ShakeRecipe, generate_shake_motion_meta
 
 JSONType = io.Custom("JSON")
 
@@ -258,7 +259,95 @@ class VideoStabilizerInverse(io.ComfyNode):
         return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
 
 
-NODE_CLASSES = [VideoStabilizerClassic, VideoStabilizerFlow, VideoStabilizerMotionApply, VideoStabilizerInverse]
+def _shake_common_inputs(middle: list) -> list:
+    """`frames_context`, `frame_rate`, <node-specific sockets>, `amount`, `speed`, `seed`
+    (video_stabilizer_shake_generator.py:27-79, video_stabilizer_shake_generator_manual.py:29-136)."""
+    slider = io.NumberDisplay.slider
+    return [
+        io.Image.Input("frames_context", display_name="Frames Context",
+                       tooltip=("The input frames are used only to read frame count and resolution. This node outputs "
+                                "motion metadata only; connect it to Video Stabilizer Motion Apply to move pixels.")),
+        io.Float.Input("frame_rate", default=16.0, min=1.0, step=0.1, display_name="Input FPS",
+                       tooltip="Fallback frame rate when the input does not carry fps metadata."),
+        *middle,
+        io.Float.Input("amount", default=1.0, min=0.0, max=3.0, step=0.05, display_name="Amount", display_mode=slider),
+        io.Float.Input("speed", default=1.0, min=0.1, max=3.0, step=0.05, display_name="Speed", display_mode=slider),
+        io.Int.Input("seed", default=0, min=0, max=0xFFFFFFFFFFFFFFFF, display_name="Seed",
+                     control_after_generate=io.ControlAfterGenerate.fixed),
+    ]
+
+
+def _shake_block(frames_context: Any, frame_rate: float, recipe: ShakeRecipe, amount: float, speed: float, seed: int,
+                 node: str, style: str):
+    context = hm._normalize_video_input(frames_context)   # only frame count and size are read; pixels are untouched
+    block = generate_shake_motion_meta(recipe=recipe, frame_count=len(context.frames), width=context.width,
+                                       height=context.height, fps=hm._resolve_fps(context, frame_rate), amount=amount,
+                                       speed=speed, seed=seed, node=node, style=style)
+    return io.NodeOutput({"motion_meta": block})
+
+
+class VideoStabilizerShakeGenerator(io.ComfyNode):
+    """Deterministic synthetic camera shake by style preset -> motion_meta (host only, no pixels)."""
+
+    @classmethod
+    def define_schema(cls) -> io.Schema:
+        schema = io.Schema(
+            node_id="video_stabilizer_shake_generator",
+            display_name="Video Stabilizer Shake Generator",
+            category="Video/Stabilization",
+            description="Generates deterministic shake motion metadata; it does not alter input frames.",
+        )
+        schema.inputs = _shake_common_inputs([
+            io.Combo.Input("style", options=list(STYLES.keys()), default="handheld", display_name="Style")])
+        schema.outputs = [JSONType.Output("motion_meta", display_name="Motion Meta")]
+        return schema
+
+    @classmethod
+    def execute(cls, frames_context: Any, frame_rate: float, style: str, amount: float, speed: float, seed: int) -> io.NodeOutput:
+        return _shake_block(frames_context, frame_rate, STYLES[style], amount, speed, seed, "shake_generator", style)
+
+
+_MANUAL_FIELDS = [  # id, step, display name (ranges come from shake_generator.FIELD_RANGE, defaults from the handheld preset)
+    ("pan", 0.01, "Pan"), ("tilt", 0.01, "Tilt"), ("roll", 0.01, "Roll"), ("zoom", 0.001, "Zoom"),
+    ("drift_freq", 0.05, "Drift Frequency"), ("tremor", 0.05, "Tremor"), ("tremor_freq", 0.5, "Tremor Frequency"),
+    ("jitter_rate", 0.1, "Jitter Rate"), ("step", 0.05, "Step"), ("randomness", 0.05, "Randomness"),
+    ("virtual_fov", 1.0, "Virtual FOV"),
+]
+
+
+class VideoStabilizerShakeGeneratorManual(io.ComfyNode):
+    """The same generator driven by explicit recipe values."""
+
+    @classmethod
+    def define_schema(cls) -> io.Schema:
+        from .shake_generator import FIELD_RANGE
+
+        schema = io.Schema(
+            node_id="video_stabilizer_shake_generator_manual",
+            display_name="Video Stabilizer Shake Generator Manual",
+            category="Video/Stabilization",
+            description="Generates deterministic shake motion metadata from manual absolute values.",
+        )
+        base = STYLES["handheld"]
+        fields = []
+        for name, step, label in _MANUAL_FIELDS:
+            extra = {"display_mode": io.NumberDisplay.slider} if name == "randomness" else {}
+            fields.append(io.Float.Input(name, default=getattr(base, name), min=FIELD_RANGE[name][0], max=FIELD_RANGE[name][1],
+                                         step=step, display_name=label, **extra))
+        schema.inputs = _shake_common_inputs(fields)
+        schema.outputs = [JSONType.Output("motion_meta", display_name="Motion Meta")]
+        return schema
+
+    @classmethod
+    def execute(cls, frames_context: Any, frame_rate: float, pan: float, tilt: float, roll: float, zoom: float,
+                drift_freq: float, tremor: float, tremor_freq: float, jitter_rate: float, step: float, randomness: float,
+                virtual_fov: float, amount: float, speed: float, seed: int) -> io.NodeOutput:
+        recipe = ShakeRecipe(pan, tilt, roll, zoom, drift_freq, tremor, tremor_freq, jitter_rate, step, randomness, virtual_fov)
+        return _shake_block(frames_context, frame_rate, recipe, amount, speed, seed, "shake_generator_manual", "manual")
+
+
+NODE_CLASSES = [VideoStabilizerClassic, VideoStabilizerFlow, VideoStabilizerMotionApply, VideoStabilizerShakeGenerator,
+                VideoStabilizerShakeGeneratorManual, VideoStabilizerInverse]
 
 
 class VideoStabilizerAmdExtension(ComfyExtension):

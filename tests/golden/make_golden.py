@@ -224,6 +224,40 @@ def main() -> None:
     small["single_frame"] = one
     (OUT / "reference_small_paths.json").write_text(json.dumps(jsonable(small)))
 
+    # ---- shake generator: full motion_meta blocks + raw components for every style and a manual
+    # recipe that exercises the jitter and walking-step layers; RNG draw order is part of the contract
+    shake: dict = {"cases": [], "errors": {}}
+    manual = sn.ShakeRecipe(pan=0.7, tilt=0.2, roll=1.3, zoom=0.01, drift_freq=0.6, tremor=0.9, tremor_freq=7.5, jitter_rate=2.0,
+                            step=1.1, randomness=0.8, virtual_fov=35.0)
+    wild = sn.ShakeRecipe(pan=9.0, tilt=-1.0, roll=0.0, zoom=1.0, drift_freq=0.0, tremor=3.0, tremor_freq=0.2, jitter_rate=9.0,
+                          step=0.0, randomness=0.0, virtual_fov=500.0)    # clamped on entry
+    plans = [(name, sn.STYLES[name], 24, (640, 360), 16.0, 1.0, 1.0, 0) for name in sn.STYLES]
+    plans += [("handheld", sn.STYLES["handheld"], 40, (1920, 1080), 24.0, 2.5, 0.4, 123456789),
+              ("walking", sn.STYLES["walking"], 33, (1080, 1920), 30.0, 0.5, 3.0, 7),
+              ("action", sn.STYLES["action"], 48, (854, 480), 12.0, 1.0, 1.0, 2 ** 40 + 3),
+              ("manual", manual, 36, (720, 576), 25.0, 1.5, 1.2, 99),
+              ("manual", wild, 20, (320, 240), 0.5, 9.0, 0.01, 5),
+              ("manual", manual, 1, (64, 48), 16.0, 1.0, 1.0, 1),
+              ("manual", manual, 0, (64, 48), 16.0, 1.0, 1.0, 1),
+              ("manual", manual, 3, (64, 48), 16.0, 1.0, 1.0, 1)]
+    for style, recipe, n, (w, h), fps, amount, speed, seed in plans:
+        comp = sn.generate_shake_components(recipe=recipe, frame_count=n, fps=fps, amount=amount, speed=speed, seed=seed)
+        blk = sn.generate_shake_motion_meta(recipe=recipe, frame_count=n, width=w, height=h, fps=fps, amount=amount, speed=speed,
+                                            seed=seed, node="shake_generator" if style != "manual" else "shake_generator_manual",
+                                            style=style)
+        shake["cases"].append({"style": style, "recipe": sn.recipe_to_dict(recipe), "frame_count": n, "size": [w, h], "fps": fps,
+                               "amount": amount, "speed": speed, "seed": seed,
+                               "components": {"pan_deg": comp.pan_deg, "tilt_deg": comp.tilt_deg, "roll_deg": comp.roll_deg,
+                                              "zoom_log": comp.zoom_log},
+                               "motion_meta": blk})
+    shake["errors"]["negative_frames"] = error_of(sn.generate_shake_motion_meta, recipe=manual, frame_count=-1, width=8, height=8,
+                                                  fps=16.0, amount=1.0, speed=1.0, seed=0)
+    shake["errors"]["zero_width"] = error_of(sn.generate_shake_motion_meta, recipe=manual, frame_count=2, width=0, height=8,
+                                             fps=16.0, amount=1.0, speed=1.0, seed=0)
+    shake["mapping"] = {"in": {k: v * 10 for k, v in sn.recipe_to_dict(manual).items()},
+                        "out": sn.recipe_to_dict(sn.recipe_from_mapping({k: v * 10 for k, v in sn.recipe_to_dict(manual).items()}))}
+    (OUT / "shake_cases.json").write_text(json.dumps(jsonable(shake)))
+
     # larger shake clips used as Motion Apply inputs for configs C3/C5 (matrices only)
     for tag, (n, w, h) in {"c3_256x1080p": (256, 1920, 1080), "c5_64x4k": (64, 3840, 2160)}.items():
         blk = sn.generate_shake_motion_meta(recipe=sn.STYLES["handheld"], frame_count=n, width=w, height=h, fps=16.0,

@@ -189,3 +189,33 @@ def test_host_math_is_pythons_libm(pkg):
         got = native.host_math(name, *args)
         want = np.array([getattr(math, name)(*[float(x[i]) for x in args]) for i in range(a.size)])
         assert np.array_equal(got, want, equal_nan=True), name
+
+
+def test_shake_generator_nodes(pkg):
+    """Schema of the two generator nodes (video_stabilizer_shake_generator.py:18-84, ..._manual.py:22-141) and one
+    execution each on the CPU (they read only frame count / size / fps of the connected clip)."""
+    import json
+
+    import torch
+
+    from vstab_amd import nodes, shake_generator as sg
+
+    s = nodes.VideoStabilizerShakeGenerator.define_schema()
+    assert s.node_id == "video_stabilizer_shake_generator" and s.display_name == "Video Stabilizer Shake Generator"
+    assert [i.id for i in s.inputs] == ["frames_context", "frame_rate", "style", "amount", "speed", "seed"]
+    assert [o.id for o in s.outputs] == ["motion_meta"]
+    m = nodes.VideoStabilizerShakeGeneratorManual.define_schema()
+    assert m.node_id == "video_stabilizer_shake_generator_manual"
+    assert [i.id for i in m.inputs] == ["frames_context", "frame_rate", "pan", "tilt", "roll", "zoom", "drift_freq", "tremor",
+                                        "tremor_freq", "jitter_rate", "step", "randomness", "virtual_fov", "amount", "speed", "seed"]
+    frames = torch.zeros((12, 48, 64, 3))
+    out = nodes.VideoStabilizerShakeGenerator.execute(frames, 24.0, "walking", 1.0, 1.0, 3)[0]
+    want = sg.generate_shake_motion_meta(recipe=sg.STYLES["walking"], frame_count=12, width=64, height=48, fps=24.0, amount=1.0,
+                                         speed=1.0, seed=3, node="shake_generator", style="walking")
+    assert json.dumps(out) == json.dumps({"motion_meta": want}) and want["frame_count"] == 12 and want["generator"]["style"] == "walking"
+    h = sg.STYLES["handheld"]
+    out2 = nodes.VideoStabilizerShakeGeneratorManual.execute({"frames": frames, "fps": 30.0}, 16.0, *h, 1.0, 1.0, 0)[0]["motion_meta"]
+    assert out2["fps"] == 30.0 and out2["generator"]["node"] == "shake_generator_manual" and out2["generator"]["style"] == "manual"
+    ref = sg.generate_shake_motion_meta(recipe=h, frame_count=12, width=64, height=48, fps=30.0, amount=1.0, speed=1.0, seed=0,
+                                        node="shake_generator", style="handheld")
+    assert out2["per_frame"] == ref["per_frame"]      # same recipe, same seed -> same motion

@@ -258,3 +258,33 @@ def test_empty_and_single_frame_paths_match_reference(pkg, hm, estimator):
         assert json.dumps(res.meta) == json.dumps(want["meta"]), (case["kind"], args)
         assert np.array_equal(np.asarray(res.frames, np.float32).reshape(nd(want["frames"]).shape), nd(want["frames"]))
         assert np.asarray(res.masks).shape == nd(want["masks"]).shape and not np.asarray(res.masks).any()
+
+
+SHAKE = json.loads((Path(__file__).parent / "golden" / "shake_cases.json").read_text())
+
+
+def test_shake_generator_matches_reference(pkg):
+    """the shake generator's components and complete motion_meta blocks equal the reference's
+    (shake_noise.py, run by tests/golden/make_golden.py) bit for bit -- same draws from default_rng(seed), same
+    floating-point operation order -- for every style, a manual recipe with jitter + walking step, clamped
+    out-of-range inputs, and 0/1/3-frame clips."""
+    from vstab_amd import shake_generator as sg
+
+    for case in SHAKE["cases"]:
+        recipe = sg.ShakeRecipe(**case["recipe"])
+        kw = dict(recipe=recipe, frame_count=case["frame_count"], fps=case["fps"], amount=case["amount"], speed=case["speed"],
+                  seed=case["seed"])
+        comp = sg.generate_shake_components(**kw)
+        for name, want in case["components"].items():
+            assert np.array_equal(comp[name], nd(want)), (case["style"], case["seed"], name)
+        w, h = case["size"]
+        blk = sg.generate_shake_motion_meta(width=w, height=h, style=case["style"],
+                                            node="shake_generator" if case["style"] != "manual" else "shake_generator_manual", **kw)
+        assert json.dumps(blk) == json.dumps(case["motion_meta"]), (case["style"], case["seed"])
+    assert {k: tuple(v) for k, v in sg.STYLES.items()} == {c["style"]: tuple(c["recipe"].values()) for c in SHAKE["cases"][:5]}
+    got = sg.recipe_to_dict(sg.recipe_from_mapping(SHAKE["mapping"]["in"]))
+    assert got == SHAKE["mapping"]["out"]
+    for key, kwargs in (("negative_frames", dict(frame_count=-1, width=8, height=8)), ("zero_width", dict(frame_count=2, width=0, height=8))):
+        with pytest.raises(ValueError) as err:
+            sg.generate_shake_motion_meta(recipe=sg.STYLES["handheld"], fps=16.0, amount=1.0, speed=1.0, seed=0, **kwargs)
+        assert str(err.value) == SHAKE["errors"][key]["message"]
