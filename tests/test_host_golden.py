@@ -288,3 +288,76 @@ def test_shake_generator_matches_reference(pkg):
         with pytest.raises(ValueError) as err:
             sg.generate_shake_motion_meta(recipe=sg.STYLES["handheld"], fps=16.0, amount=1.0, speed=1.0, seed=0, **kwargs)
         assert str(err.value) == SHAKE["errors"][key]["message"]
+
+
+def _sticky_walk_reference(records, requested):
+    """Per-pair loop in the shape of flow.py:324-339 + :156-210: try modes from the active one downwards, take the
+    first accepted candidate, make its mode sticky; no candidate at all -> identity reported as translation."""
+    order = {"perspective": ["perspective", "similarity", "translation"], "similarity": ["similarity", "translation"],
+             "translation": ["translation"]}
+    active, out = requested, []
+    for rec in records:
+        pick = None
+        for mode in order[active]:
+            cand = rec.get(mode)
+            if cand is not None and cand["accepted"]:
+                pick = (cand["matrix"], mode, cand["confidence"], cand["residual"])
+                break
+        if pick is None:
+            pick = (np.eye(3, dtype=np.float32), "translation", 0.0, 0.0)
+        if pick[1] != active:
+            active = pick[1]
+        out.append(pick)
+    return out, active
+
+
+@pytest.mark.parametrize("requested", ["translation", "similarity", "perspective"])
+def test_sticky_mode_selection_equals_sequential_walk(pkg, requested):
+    """`select_transitions` (run-length walk on the record table, with its all-accepted fast path) against a plain
+    per-pair loop on random candidate tables: rejections, missing candidates, pairs with nothing computed."""
+    from vstab_amd import flow_pipeline as fp
+
+    rng = np.random.default_rng({"translation": 1, "similarity": 2, "perspective": 3}[requested])
+    modes = ["translation", "similarity", "perspective"]
+    for trial in range(60):
+        pairs = int(rng.integers(1, 40))
+        p_reject = [0.0, 0.05, 0.5][trial % 3]
+        records = []
+        for _ in range(pairs):
+            rec = {}
+            if rng.random() >= p_reject * 0.3:                       # otherwise: fewer than 12 valid samples, nothing computed
+                for mi, name in enumerate(modes[: modes.index(requested) + 1]):
+                    if name != "translation" and rng.random() < p_reject * 0.2:
+                        continue                                      # estimator returned no model
+                    rec[name] = {"matrix": rng.normal(0, 1, (3, 3)).astype(np.float32), "confidence": float(rng.random()),
+                                 "residual": float(rng.random()), "accepted": bool(name == "translation" or rng.random() >= p_reject)}
+            records.append(rec)
+        want, want_active = _sticky_walk_reference(records, requested)
+        mats, used, confs, resids, active = fp.select_transitions(records, requested)
+        assert active == want_active and used == [w[1] for w in want]
+        assert confs == [w[2] for w in want] and resids == [w[3] for w in want]
+        assert np.array_equal(mats, np.stack([w[0] for w in want]))
+
+
+def test_progress_replay_equals_per_item_loop(pkg):
+    """flow.py:347-351 / 589-593: one update per 10 finished items plus one for the remainder."""
+    from vstab_amd import flow_pipeline as fp
+
+    class Bar:
+        def __init__(self):
+            self.calls = []
+
+        def update_absolute(self, value, total):
+            self.calls.append((value, total))
+
+    for count in list(range(0, 35)) + [99, 100, 101, 255, 256]:
+        for done0 in (0, 7):
+            want, pending, done = [], 0, done0
+            for idx in range(count):
+                pending += 1
+                if pending >= 10 or idx == count - 1:
+                    done += pending
+                    want.append((done, 1000))
+                    pending = 0
+            bar = Bar()
+            assert fp._replay_progress(bar, done0, count, 1000) == done0 + count and bar.calls == want, count
