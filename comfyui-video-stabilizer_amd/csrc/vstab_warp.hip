@@ -218,10 +218,14 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const unsigned tr = t - frame * tiles_per_frame;
     const int tile_y = tr / a.tiles_x, tile_x = tr - tile_y * a.tiles_x;
     const int tx = threadIdx.x % TILE_TX, ty = threadIdx.x / TILE_TX;
-    const int x0 = tile_x * TILE_W + tx * TILE_PX;
+    // Pixel p of a thread is x0 + p * TILE_TX: the lanes of a wavefront cover CONSECUTIVE output pixels, so one load
+    // instruction of the bilinear taps touches ~13 cache lines (24 B per lane at a 12-B lane stride) instead of 48
+    // (at the 48-B stride of 4 consecutive pixels per thread) -- the texture addresser was 83 % busy that way (PMC
+    // TA_BUSY) and limited the read side to 2.8 TB/s -- and the stores are whole lines (12 B per lane, contiguous).
+    const int x0 = tile_x * TILE_W + tx;
     const int y = tile_y * TILE_H + ty;
     const bool active = (y < a.dh) && (x0 < a.dw);
-    const int npx = active ? (a.dw - x0 < TILE_PX ? a.dw - x0 : TILE_PX) : 0;
+    const int npx = active ? (a.dw - x0 + TILE_TX - 1) / TILE_TX : 0;   // pixels x0 + p*TILE_TX < dw (capped at TILE_PX below)
 
     const float* __restrict__ S = a.src + (size_t)frame * a.sh * a.sw * 3;
     const int S_count = BLUR ? a.samples : 1;
@@ -233,13 +237,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     for (int p = 0; p < TILE_PX; p++) { acc[p][0] = acc[p][1] = acc[p][2] = 0.f; cov[p] = 0.f; }
 
     if (active) {
-        // OpenCV evaluates the row-start terms per 64-wide column block (x0 % 4 == 0, so the
-        // 4 pixels of a thread never straddle a block).
-        int xb;
-        if (a.bw0 >= a.dw) xb = 0;
-        else if (a.bw0_pow2) xb = x0 & ~(a.bw0 - 1);
-        else xb = (x0 / a.bw0) * a.bw0;
-        const double dxb = (double)xb, dy = (double)y;
+        const double dy = (double)y;
 
         for (int k = 0; k < nxf; k++) {
             const WarpXform* __restrict__ xf = a.xf + (size_t)frame * nxf + k;
@@ -247,32 +245,33 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
             const double m3 = xf->m[3], m4 = xf->m[4], m5 = xf->m[5];
             const double m6 = xf->m[6], m7 = xf->m[7], m8 = xf->m[8];
             const bool affine = xf->affine != 0;
-            const double X0 = m0 * dxb + m1 * dy + m2;
-            const double Y0 = m3 * dxb + m4 * dy + m5;
-            const double W0 = m6 * dxb + m7 * dy + m8;
+            // OpenCV evaluates the row-start terms X0, Y0, W0 once per 64-wide column block (xb) and adds m * (x - xb)
+            // per pixel; a thread's pixels lie in up to TILE_PX different blocks, so the terms are formed per pixel.
             float mf[9];
             if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
 #pragma unroll
                 for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
             }
-            // Fast path (the common case): affine map whose 1/32-px coordinates stay far inside the range where
-            // OpenCV's INT clamp and short saturation are no-ops (linear in x, so the two end pixels bound all 4).
-            bool small = false;
-            if (affine && !(SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR)) {
-                const double lim = 1.0e6;
-                const double d0 = (double)(x0 - xb), d3 = d0 + 3.0;
-                const double xa = (X0 + m0 * d0) * xf->wq, xz = (X0 + m0 * d3) * xf->wq;
-                const double ya = (Y0 + m3 * d0) * xf->wq, yz = (Y0 + m3 * d3) * xf->wq;
-                small = __builtin_fabs(xa) < lim && __builtin_fabs(xz) < lim && __builtin_fabs(ya) < lim && __builtin_fabs(yz) < lim;
-            }
+            const bool fast_ok = affine && !(SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR);
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) {
                 if (p >= npx) continue;
-                const int x = x0 + p;
+                const int x = x0 + p * TILE_TX;
+                int xb;
+                if (a.bw0 >= a.dw) xb = 0;
+                else if (a.bw0_pow2) xb = x & ~(a.bw0 - 1);
+                else xb = (x / a.bw0) * a.bw0;
+                const double dxb = (double)xb;
+                const double X0 = m0 * dxb + m1 * dy + m2;
+                const double Y0 = m3 * dxb + m4 * dy + m5;
+                const double W0 = m6 * dxb + m7 * dy + m8;
                 const double dx1 = (double)(x - xb);
                 const double Xn = X0 + m0 * dx1, Yn = Y0 + m3 * dx1;
                 Px v;
                 float c = 0.f;
+                // Fast path (the common case): affine map whose 1/32-px coordinates stay far inside the range where
+                // OpenCV's INT clamp and short saturation are no-ops.
+                const bool small = fast_ok && __builtin_fabs(Xn * xf->wq) < 1.0e6 && __builtin_fabs(Yn * xf->wq) < 1.0e6;
                 if (small) {
                     const int X = round_small(Xn * xf->wq), Y = round_small(Yn * xf->wq);
                     v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
@@ -334,27 +333,16 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     }
 
     if (active) {
-        const size_t pix = ((size_t)frame * a.dh + y) * a.dw + x0;
-        float* __restrict__ D = a.dst + pix * 3;
-        if (a.vec_store) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4* D4 = reinterpret_cast<f4*>(D);
-            const f4 v0 = {acc[0][0], acc[0][1], acc[0][2], acc[1][0]}, v1 = {acc[1][1], acc[1][2], acc[2][0], acc[2][1]},
-                     v2 = {acc[2][2], acc[3][0], acc[3][1], acc[3][2]}, vm = {mk[0], mk[1], mk[2], mk[3]};
-            if (a.nt_store) {
-                __builtin_nontemporal_store(v0, D4); __builtin_nontemporal_store(v1, D4 + 1); __builtin_nontemporal_store(v2, D4 + 2);
-                if (WITH_MASK) __builtin_nontemporal_store(vm, reinterpret_cast<f4*>(a.mask + pix));
-            } else {
-                D4[0] = v0; D4[1] = v1; D4[2] = v2;
-                if (WITH_MASK) *reinterpret_cast<f4*>(a.mask + pix) = vm;
-            }
-        } else {
+        const size_t row = ((size_t)frame * a.dh + y) * a.dw;
+        typedef float f3 __attribute__((ext_vector_type(3)));
 #pragma unroll
-            for (int p = 0; p < TILE_PX; p++) {
-                if (p >= npx) continue;
-                D[p * 3 + 0] = acc[p][0]; D[p * 3 + 1] = acc[p][1]; D[p * 3 + 2] = acc[p][2];
-                if (WITH_MASK) a.mask[pix + p] = mk[p];
-            }
+        for (int p = 0; p < TILE_PX; p++) {
+            if (p >= npx) continue;
+            const size_t pix = row + x0 + p * TILE_TX;
+            // 12 B per lane, consecutive lanes -> consecutive pixels: every store instruction writes whole lines
+            f3 rgb = {acc[p][0], acc[p][1], acc[p][2]};
+            __builtin_memcpy(a.dst + pix * 3, &rgb, 12);
+            if (WITH_MASK) a.mask[pix] = mk[p];
         }
     }
 
