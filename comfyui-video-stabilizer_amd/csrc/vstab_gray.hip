@@ -33,57 +33,32 @@ __device__ __forceinline__ int sat_u8_round(float v)
 }
 
 // Integer-ratio INTER_AREA (K x K boxes) fused with the gray conversion. K == 1: gray only.
+// One workgroup per output row; thread t produces the pixels t, t + 256, ...: the lanes of a wavefront read
+// CONSECUTIVE K-pixel groups (K * 12 B apart), so one load instruction touches K * 12 * 64 contiguous bytes
+// instead of 64 scattered 16-B pieces (the texture addresser, not HBM, was the limit with 4 pixels per thread).
 template <int K>
 __global__ __launch_bounds__(256) void gray_area_int_kernel(const float* __restrict__ frames, uint8_t* __restrict__ out,
                                                              int n, int sh, int sw, int dh, int dw, int body)
 {
-    const int groups_x = (dw + 3) >> 2;
-    const long long total = (long long)n * dh * groups_x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int gx = (int)(t % groups_x);
-        const long long r = t / groups_x;
-        const int y = (int)(r % dh);
-        const int f = (int)(r / dh);
-        const int x0 = gx * 4;
-        const int npx = dw - x0 < 4 ? dw - x0 : 4;
-        int sum[4] = {0, 0, 0, 0};
-        const float* base = frames + ((size_t)f * sh + (size_t)y * K) * sw * 3 + (size_t)x0 * K * 3;
-        if (npx == 4) {
+    const int y = blockIdx.x % dh, f = blockIdx.x / dh;
+    const float* rowbase = frames + ((size_t)f * sh + (size_t)y * K) * sw * 3;
+    uint8_t* D = out + ((size_t)f * dh + y) * dw;
+#pragma unroll 4
+    for (int x = threadIdx.x; x < dw; x += 256) {
+        int sum = 0;
+        const float* base = rowbase + (size_t)x * K * 3;
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                float row[4 * K * 3];
-                __builtin_memcpy(row, base + (size_t)j * sw * 3, sizeof(row));
+        for (int j = 0; j < K; j++) {
+            float row[K * 3];
+            __builtin_memcpy(row, base + (size_t)j * sw * 3, sizeof(row));
 #pragma unroll
-                for (int p = 0; p < 4; p++)
-#pragma unroll
-                    for (int i = 0; i < K; i++) {
-                        const int xi = (x0 + p) * K + i;
-                        const float* px = row + (p * K + i) * 3;
-                        sum[p] += gray_u8(px[0], px[1], px[2], xi < body);
-                    }
-            }
-        } else {
-            for (int j = 0; j < K; j++)
-                for (int p = 0; p < npx; p++)
-                    for (int i = 0; i < K; i++) {
-                        const int xi = (x0 + p) * K + i;
-                        const float* px = base + (size_t)j * sw * 3 + (size_t)(p * K + i) * 3;
-                        sum[p] += gray_u8(px[0], px[1], px[2], xi < body);
-                    }
+            for (int i = 0; i < K; i++) sum += gray_u8(row[i * 3], row[i * 3 + 1], row[i * 3 + 2], (x * K + i) < body);
         }
-        int o[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            if (K == 1) o[p] = sum[p];
-            else if (K == 2) o[p] = (sum[p] + 2) >> 2;
-            else o[p] = sat_u8_round(sum[p] * (1.f / (K * K)));
-        }
-        uint8_t* D = out + ((size_t)f * dh + y) * dw + x0;
-        if (npx == 4 && ((reinterpret_cast<uintptr_t>(D) & 3) == 0)) {
-            *reinterpret_cast<uint32_t*>(D) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
-        } else {
-            for (int p = 0; p < npx; p++) D[p] = (uint8_t)o[p];
-        }
+        int o;
+        if (K == 1) o = sum;
+        else if (K == 2) o = (sum + 2) >> 2;
+        else o = sat_u8_round(sum * (1.f / (K * K)));
+        D[x] = (uint8_t)o;
     }
 }
 
@@ -189,8 +164,7 @@ extern "C" int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, 
     KernelTimer timer(ctx, "gray");
 
     if (work_h == src_h && work_w == src_w) {
-        const long long items = (long long)n * work_h * ((work_w + 3) / 4);
-        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3(grid_for(items)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
+        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
         VSTAB_HIP(hipGetLastError());
         return 0;
     }
@@ -199,11 +173,10 @@ extern "C" int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, 
     const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
     const bool fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
     if (fast && isx == isy && (isx == 2 || isx == 4)) {
-        const long long items = (long long)n * work_h * ((work_w + 3) / 4);
         if (isx == 2)
-            hipLaunchKernelGGL((gray_area_int_kernel<2>), dim3(grid_for(items)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
+            hipLaunchKernelGGL((gray_area_int_kernel<2>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
         else
-            hipLaunchKernelGGL((gray_area_int_kernel<4>), dim3(grid_for(items)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
+            hipLaunchKernelGGL((gray_area_int_kernel<4>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
         VSTAB_HIP(hipGetLastError());
         return 0;
     }
@@ -212,8 +185,7 @@ extern "C" int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, 
     if (ctx->d_gray_tmp.reserve(full)) return 1;
     uint8_t* tmp = static_cast<uint8_t*>(ctx->d_gray_tmp.ptr);
     {
-        const long long items = (long long)n * src_h * ((src_w + 3) / 4);
-        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3(grid_for(items)), dim3(256), 0, st, frames, tmp, n, src_h, src_w, src_h, src_w, body);
+        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3((unsigned)(n * src_h)), dim3(256), 0, st, frames, tmp, n, src_h, src_w, src_h, src_w, body);
         VSTAB_HIP(hipGetLastError());
     }
     const long long out_items = (long long)n * work_h * work_w;
