@@ -13,6 +13,7 @@
 //   * blockIdx is remapped so that the 8 XCDs (private L2 each) own contiguous runs of tiles
 //   * padding-pixel count: wave shuffle reduction -> LDS -> one atomic per block, only if non-zero
 #include "vstab_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -40,8 +41,6 @@ struct WarpArgs {
     int samples;      // 1 for the plain warp
     int nxf_per_frame;  // sample matrices stored per frame (1 for a single-frame blur clip)
     float b0, b1, b2;   // border colour
-    int vec_store;    // 1 if 16-B vector stores are legal (dw % 4 == 0, aligned bases)
-    int nt_store;     // experiment: nontemporal stores
 };
 
 __device__ __forceinline__ int clamp_round_i32(double v)
@@ -376,8 +375,10 @@ void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t s
 template <bool BLUR>
 int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t st)
 {
-    const int tx = 32;   // 128 x 8 tile: best of {8,16,32,64} threads along x (profiles/r01_warp_tile_sweep.md)
-    a.nt_store = 0;      // nontemporal stores measured neutral
+    // threads along x of the 256-thread tile: 32 (128 x 8 px) by default; VSTAB_WARP_TX = 8|16|64 for sweeps
+    // (profiles/r01_warp_tile_sweep.md)
+    int tx = 32;
+    if (const char* e = getenv("VSTAB_WARP_TX")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 64) tx = v; }
     a.tiles_x = (a.dw + tx * TILE_PX - 1) / (tx * TILE_PX);
     a.tiles_y = (a.dh + 256 / tx - 1) / (256 / tx);
     const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
@@ -424,8 +425,6 @@ void fill_geometry(WarpArgs& a, int n, int sh, int sw, int dh, int dw, const flo
     a.bw0 = bw0;
     a.bw0_pow2 = (bw0 & (bw0 - 1)) == 0;
     a.b0 = border[0]; a.b1 = border[1]; a.b2 = border[2];
-    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
-    a.vec_store = ((dw & 3) == 0 && aligned) ? 1 : 0;
 }
 
 }  // namespace
