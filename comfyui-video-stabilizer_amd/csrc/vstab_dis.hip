@@ -539,64 +539,6 @@ __device__ __forceinline__ void vr_deriv2_px(const VrBufs& b, long long t, int x
     b.Iyy[t] = b.Iy[yd] - b.Iy[yu];
 }
 
-__device__ __forceinline__ void vr_weights_px(const VrBufs& b, long long t, int x, int y, int h, int w, float alpha2, float eps2)
-{
-    const long long qr = (x + 1 < w) ? t + 1 : t;
-    const long long qd = (y + 1 < h) ? t + w : t;
-    const float ux = b.tU[qr] - b.tU[t], vx = b.tV[qr] - b.tV[t];
-    const float uy = b.tU[qd] - b.tU[t], vy = b.tV[qd] - b.tV[t];
-    b.wgt[t] = alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
-}
-
-__device__ __forceinline__ void vr_system_px(const VrBufs& b, const float* __restrict__ U, const float* __restrict__ V, long long q, int x,
-                                             int y, int h, int w, float delta2, float gamma2, float zeta2, float eps2)
-{
-    const float Ix = b.Ix[q], Iy = b.Iy[q], Iz = b.Iz[q], Ixx = b.Ixx[q], Ixy = b.Ixy[q], Iyy = b.Iyy[q], Ixz = b.Ixz[q], Iyz = b.Iyz[q];
-    const float du = b.dU[q], dv = b.dV[q];
-    float a11, a12, a22, B1, B2;
-    {
-        float derivNorm = Ix * Ix + Iy * Iy + zeta2;
-        float Ik1z = Iz + Ix * du + Iy * dv;
-        float weight = delta2 / __builtin_sqrtf(Ik1z * Ik1z / derivNorm + eps2);
-        a11 = weight * (Ix * Ix / derivNorm) + zeta2;
-        a12 = weight * (Ix * Iy / derivNorm);
-        a22 = weight * (Iy * Iy / derivNorm) + zeta2;
-        B1 = -weight * (Iz * Ix / derivNorm);
-        B2 = -weight * (Iz * Iy / derivNorm);
-        derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
-        float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
-        float Ik1zx = Ixz + Ixx * du + Ixy * dv;
-        float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-        weight = gamma2 / __builtin_sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
-        a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-        a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-        a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-        B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-        B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
-    }
-    const bool red = ((x + y) & 1) == 0;
-    const bool has_r = x + 1 < w, has_l = x > 0, has_d = y + 1 < h, has_u = y > 0;
-    const float wq = b.wgt[q], uq = U[q], vq = V[q];
-    float own_hu = 0, own_hv = 0, left_hu = 0, left_hv = 0, wl = 0;
-    if (has_r) { own_hu = wq * (U[q + 1] - uq); own_hv = wq * (V[q + 1] - vq); }
-    if (has_l) { wl = b.wgt[q - 1]; left_hu = wl * (uq - U[q - 1]); left_hv = wl * (vq - V[q - 1]); }
-    float own_vu = 0, own_vv = 0, up_vu = 0, up_vv = 0, wu = 0;
-    if (has_d) { own_vu = wq * (U[q + w] - uq); own_vv = wq * (V[q + w] - vq); }
-    if (has_u) { wu = b.wgt[q - w]; up_vu = wu * (uq - U[q - w]); up_vv = wu * (vq - V[q - w]); }
-    if (red) {
-        if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-        if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-        if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-        if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-    } else {
-        if (has_l) { B1 -= left_hu; a11 += wl; B2 -= left_hv; a22 += wl; }
-        if (has_r) { B1 += own_hu; a11 += wq; B2 += own_hv; a22 += wq; }
-        if (has_u) { B1 -= up_vu; a11 += wu; B2 -= up_vv; a22 += wu; }
-        if (has_d) { B1 += own_vu; a11 += wq; B2 += own_vv; a22 += wq; }
-    }
-    b.A11[q] = a11; b.A12[q] = a12; b.A22[q] = a22; b.b1[q] = B1; b.b2[q] = B2;
-}
-
 // ---- bilinear f32 resize (flow upsampling between levels), result scaled by `mul` ------------
 __device__ __forceinline__ void lin_coord(int d, double scale, int ssize, int& s0, float& f)
 {
