@@ -9,11 +9,12 @@
 // depends on its SIMD dispatch), so both sides are compared bit for bit.
 //
 // Mapping to the machine:
-//   * min-eigenvalue map: separable 21x21 box sums of the Sobel products, fp64 accumulators; the row pass
-//     stages one image row segment (+10 px halo each side) of dx^2, dxdy, dy^2 in LDS
-//   * corner candidates (3x3 maxima above quality*max) are appended as 64-bit keys (strength bits << 32 |
-//     pixel index); one 1024-thread block per frame sorts them (bitonic, in place) and one wavefront runs
-//     OpenCV's greedy minimum-distance selection with a 64-wide parallel distance test per candidate
+//   * min-eigenvalue map: one 1024-thread workgroup per 32 x 32 tile keeps the Sobel products of the tile + box
+//     halo and their fp64 row sums in LDS (separable 21x21 box sums, fp64 accumulators, fixed summation order)
+//   * corner candidates (3x3 maxima above quality*max) become 64-bit keys (strength bits << 32 | pixel index);
+//     their slots come from a count / scan / write pass pair (no per-candidate atomics); one 1024-thread block per
+//     frame sorts them (bitonic, in place) and one wavefront runs OpenCV's greedy minimum-distance selection with
+//     a 64-wide parallel distance test per candidate
 //   * pyramidal LK: one wavefront per tracked point, the 31x31 window lives in registers (16 px per lane),
 //     the 2x2 normal matrix / mismatch vector are exact integer wave reductions (64-bit)
 #include "vstab_internal.h"
@@ -49,32 +50,6 @@ __device__ __forceinline__ void sobel_cov(const uint8_t* __restrict__ img, int h
     cxx = dx * dx; cxy = dx * dy; cyy = dy * dy;
 }
 
-// grid (ceil(w/ROW_T), h, frames): horizontal box sums of the three products -> three fp64 planes
-__global__ __launch_bounds__(ROW_T) void eig_rows_kernel(const uint8_t* __restrict__ gray, int h, int w, int block, float s,
-                                                         double* __restrict__ rows /*[3][frames][h][w]*/, size_t plane)
-{
-    __shared__ float c0[ROW_T + MAX_BLOCK], c1[ROW_T + MAX_BLOCK], c2[ROW_T + MAX_BLOCK];
-    const int r = block / 2;
-    const int x0 = blockIdx.x * ROW_T, y = blockIdx.y, f = blockIdx.z;
-    const uint8_t* img = gray + (size_t)f * h * w;
-    const float k2 = s * 2.f;
-    for (int i = threadIdx.x; i < ROW_T + block - 1; i += ROW_T) {
-        const int xs = reflect101(x0 - r + i, w);
-        float a, b, c;
-        sobel_cov(img, h, w, xs, y, s, k2, a, b, c);
-        c0[i] = a; c1[i] = b; c2[i] = c;
-    }
-    __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= w) return;
-    double a = 0, b = 0, c = 0;
-    for (int k = 0; k < block; k++) {
-        a += (double)c0[threadIdx.x + k]; b += (double)c1[threadIdx.x + k]; c += (double)c2[threadIdx.x + k];
-    }
-    const size_t o = ((size_t)f * h + y) * w + x;
-    rows[o] = a; rows[plane + o] = b; rows[2 * plane + o] = c;
-}
-
 __device__ __forceinline__ unsigned float_order_key(float v)
 {
     const unsigned b = __float_as_uint(v);
@@ -85,25 +60,56 @@ __device__ __forceinline__ float float_from_order_key(unsigned k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// grid (ceil(w/ROW_T), h, frames): vertical box sums -> min eigenvalue; per-frame maximum
-__global__ __launch_bounds__(ROW_T) void eig_cols_kernel(const double* __restrict__ rows, size_t plane, int h, int w, int block,
-                                                         float* __restrict__ eig, unsigned* __restrict__ max_key)
+// Fused min-eigenvalue map: one 256-thread workgroup per 32 x 32 output tile.  The Sobel products of the tile plus
+// its box-filter halo are formed once in LDS (f32), summed along x into fp64 row sums in LDS, then along y -- the
+// summation orders of the two-pass version (k ascending), so the bits are the same, but the 504 B per pixel of fp64
+// row sums never travel through HBM.  grid (tiles_x, tiles_y, frames); dynamic LDS = cov + row sums.
+constexpr int EIG_TILE = 32;
+constexpr int EIG_T = 1024;   // threads: the three phases are latency-bound loops over LDS, 32 waves per CU hide it
+__global__ __launch_bounds__(EIG_T) void eig_tile_kernel(const uint8_t* __restrict__ gray, int h, int w, int block, float s,
+                                                       float* __restrict__ eig, unsigned* __restrict__ max_key)
 {
-    __shared__ unsigned s_max[ROW_T / 64];
+    extern __shared__ unsigned char eig_lds[];
+    __shared__ unsigned s_max[EIG_T / 64];
     const int r = block / 2;
-    const int x = blockIdx.x * ROW_T + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    unsigned key = 0;
-    if (x < w) {
+    const int ext = EIG_TILE + block - 1;                 // tile + halo, both directions
+    float* cov = reinterpret_cast<float*>(eig_lds);       // [3][ext][ext]
+    double* rows = reinterpret_cast<double*>(eig_lds + (((size_t)3 * ext * ext * sizeof(float) + 15) & ~size_t(15)));   // [3][ext][EIG_TILE]
+    const int x0 = blockIdx.x * EIG_TILE, y0 = blockIdx.y * EIG_TILE, f = blockIdx.z;
+    const uint8_t* img = gray + (size_t)f * h * w;
+    const float k2 = s * 2.f;
+    const int cplane = ext * ext;
+    for (int k = threadIdx.x; k < cplane; k += EIG_T) {
+        const int ly = k / ext, lx = k - ly * ext;
+        float a, b, c;
+        sobel_cov(img, h, w, reflect101(x0 - r + lx, w), reflect101(y0 - r + ly, h), s, k2, a, b, c);
+        cov[k] = a; cov[cplane + k] = b; cov[2 * cplane + k] = c;
+    }
+    __syncthreads();
+    const int rplane = ext * EIG_TILE;
+    for (int k = threadIdx.x; k < rplane; k += EIG_T) {
+        const int ly = k / EIG_TILE, lx = k - ly * EIG_TILE;
+        const float* p = cov + ly * ext + lx;
         double a = 0, b = 0, c = 0;
-        for (int k = -r; k < block - r; k++) {
-            const size_t o = ((size_t)f * h + reflect101(y + k, h)) * w + x;
-            a += rows[o]; b += rows[plane + o]; c += rows[2 * plane + o];
+        for (int q = 0; q < block; q++) { a += (double)p[q]; b += (double)p[cplane + q]; c += (double)p[2 * cplane + q]; }
+        rows[k] = a; rows[rplane + k] = b; rows[2 * rplane + k] = c;
+    }
+    __syncthreads();
+    unsigned key = 0;
+    for (int k = threadIdx.x; k < EIG_TILE * EIG_TILE; k += EIG_T) {
+        const int ly = k / EIG_TILE, lx = k - ly * EIG_TILE;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < w && y < h) {
+            const double* p = rows + ly * EIG_TILE + lx;
+            double a = 0, b = 0, c = 0;
+            for (int q = 0; q < block; q++) { a += p[q * EIG_TILE]; b += p[rplane + q * EIG_TILE]; c += p[2 * rplane + q * EIG_TILE]; }
+            const float fa = (float)a * 0.5f, fb = (float)b, fc = (float)c * 0.5f;
+            const float t = fa - fc;
+            const float e = (fa + fc) - __builtin_sqrtf(__builtin_fmaf(fb, fb, t * t));
+            eig[((size_t)f * h + y) * w + x] = e;
+            const unsigned ke = float_order_key(e);
+            key = ke > key ? ke : key;
         }
-        const float fa = (float)a * 0.5f, fb = (float)b, fc = (float)c * 0.5f;
-        const float t = fa - fc;
-        const float e = (fa + fc) - __builtin_sqrtf(__builtin_fmaf(fb, fb, t * t));
-        eig[((size_t)f * h + y) * w + x] = e;
-        key = float_order_key(e);
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_down(key, sft); key = o > key ? o : key; }
@@ -111,35 +117,85 @@ __global__ __launch_bounds__(ROW_T) void eig_cols_kernel(const double* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned m = s_max[0];
-        for (int i = 1; i < ROW_T / 64; i++) m = s_max[i] > m ? s_max[i] : m;
+        for (int i = 1; i < EIG_T / 64; i++) m = s_max[i] > m ? s_max[i] : m;
         atomicMax(&max_key[f], m);
     }
 }
 
-// grid (ceil(w/ROW_T), h, frames): thresholded 3x3 maxima of the interior -> candidate keys
+// Thresholded 3x3 maxima of the interior -> candidate keys.  Slots are assigned without atomics (a returning atomic
+// on one counter per frame serialises: ~0.4 us per allocation, 0.7-0.8 ms per clip): a first pass counts the
+// candidates of every row, a scan turns the counts into row offsets, a second pass recomputes the same test and
+// writes each candidate to its slot.  grid (h - 2, frames), one workgroup per interior row.
+template <bool WRITE>
 __global__ __launch_bounds__(ROW_T) void corner_collect_kernel(const float* __restrict__ eig, const unsigned* __restrict__ max_key, int h, int w,
                                                                double quality, unsigned long long* __restrict__ cand, size_t cap,
-                                                               int* __restrict__ cand_count)
+                                                               int* __restrict__ row_count /*[frames][h]: counts, then offsets*/)
 {
-    const int x = blockIdx.x * ROW_T + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+    __shared__ int s_wave[ROW_T / 64];
+    __shared__ int s_base;
+    const int y = blockIdx.x + 1, f = blockIdx.y;
     const float thr = (float)((double)float_from_order_key(max_key[f]) * quality);
-    const float* E = eig + (size_t)f * h * w;
-    float v = E[(size_t)y * w + x];
-    v = v > thr ? v : 0.f;
-    if (v == 0.f) return;
-    float m = v;
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-            float q = E[(size_t)(y + dy) * w + x + dx];
-            q = q > thr ? q : 0.f;
-            m = q > m ? q : m;
+    const float* r1 = eig + ((size_t)f * h + y) * w;
+    const float* r0 = r1 - w;
+    const float* r2 = r1 + w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int running = WRITE ? row_count[(size_t)f * h + y] : 0;   // WRITE: first slot of this row; else: count so far
+    for (int xb = 1; xb < w - 1; xb += ROW_T) {
+        const int x = xb + (int)threadIdx.x;
+        float v = 0.f;
+        bool is_max = false;
+        if (x < w - 1) {
+            v = r1[x];
+            v = v > thr ? v : 0.f;
+            if (v != 0.f) {
+                float m = v;
+#define CC_TAP(p) { float q = (p); q = q > thr ? q : 0.f; m = q > m ? q : m; }
+                CC_TAP(r0[x - 1]) CC_TAP(r0[x]) CC_TAP(r0[x + 1]) CC_TAP(r1[x - 1]) CC_TAP(r1[x + 1]) CC_TAP(r2[x - 1]) CC_TAP(r2[x]) CC_TAP(r2[x + 1])
+#undef CC_TAP
+                is_max = (v == m);
+            }
         }
-    if (v != m) return;
-    const int slot = atomicAdd(&cand_count[f], 1);
-    cand[(size_t)f * cap + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * w + x);   // v > 0: bits are monotone
+        const unsigned long long vote = __ballot(is_max);
+        if (lane == 0) s_wave[wave] = __popcll(vote);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < ROW_T / 64; k++) { const int c = s_wave[k]; before += (k < wave) ? c : 0; total += c; }
+        if (WRITE && is_max) {
+            const int slot = running + before + __popcll(vote & ((1ull << lane) - 1ull));
+            cand[(size_t)f * cap + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * w + x);   // v > 0: bits are monotone
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (!WRITE && threadIdx.x == 0) row_count[(size_t)f * h + y] = running;
+    (void)s_base;
+}
+
+// one workgroup per frame: exclusive scan of the row counts (rows 1 .. h-2) in place, total -> cand_count[f]
+__global__ __launch_bounds__(256) void corner_scan_kernel(int* __restrict__ row_count, int h, int* __restrict__ cand_count)
+{
+    __shared__ int s_part[256];
+    const int f = blockIdx.x;
+    int* rc = row_count + (size_t)f * h;
+    const int per = (h + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, h);
+    int sum = 0;
+    for (int r = lo; r < hi; r++) sum += (r >= 1 && r < h - 1) ? rc[r] : 0;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < 256; i++) { const int v = s_part[i]; s_part[i] = acc; acc += v; }
+        cand_count[f] = acc;
+    }
+    __syncthreads();
+    int acc = s_part[threadIdx.x];
+    for (int r = lo; r < hi; r++) {
+        const int c = (r >= 1 && r < h - 1) ? rc[r] : 0;
+        rc[r] = acc;
+        acc += c;
+    }
 }
 
 constexpr int SEL_T = 1024;
@@ -451,30 +507,40 @@ extern "C" int vstab_gftt_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int 
     const size_t px = (size_t)h * w;
     size_t cap = 1;
     while (cap < px) cap <<= 1;                 // bitonic sort pads to a power of two in place
-    // frames per pass: keep the fp64 row planes + keys under ~1 GiB
-    const size_t per_frame = px * (3 * sizeof(double) + sizeof(float)) + cap * sizeof(unsigned long long) + 64;
+    // frames per pass: keep the eigenvalue maps + candidate keys under ~1 GiB
+    const size_t per_frame = px * sizeof(float) + cap * sizeof(unsigned long long) + sizeof(int) * (size_t)h + 64;
     int chunk = (int)((size_t(1) << 30) / per_frame);
     chunk = chunk < 1 ? 1 : (chunk > n ? n : chunk);
-    const size_t rows_b = align256(3 * px * chunk * sizeof(double)), eig_b = align256(px * chunk * sizeof(float));
-    const size_t key_b = align256(cap * chunk * sizeof(unsigned long long)), small_b = align256(sizeof(unsigned) * chunk) + align256(sizeof(int) * chunk);
+    const size_t rows_b = 0, eig_b = align256(px * chunk * sizeof(float));
+    const size_t key_b = align256(cap * chunk * sizeof(unsigned long long)), small_b = align256(sizeof(unsigned) * chunk) + align256(sizeof(int) * chunk) +
+                 align256(sizeof(int) * (size_t)chunk * h);
     if (ctx->d_dis.reserve(rows_b + eig_b + key_b + small_b)) return 1;
     char* base = static_cast<char*>(ctx->d_dis.ptr);
-    double* rows = reinterpret_cast<double*>(base);
     float* eig = reinterpret_cast<float*>(base + rows_b);
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + rows_b + eig_b);
     unsigned* max_key = reinterpret_cast<unsigned*>(base + rows_b + eig_b + key_b);
     int* cand_count = reinterpret_cast<int*>(base + rows_b + eig_b + key_b + align256(sizeof(unsigned) * chunk));
+    int* row_count = reinterpret_cast<int*>(base + rows_b + eig_b + key_b + align256(sizeof(unsigned) * chunk) + align256(sizeof(int) * chunk));
     const float s = (float)(1.0 / (4.0 * block_size * 255.0));
     KernelTimer timer(ctx, "gftt");
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int fc = (n - f0) < chunk ? (n - f0) : chunk;
-        const size_t plane = px * fc;
         VSTAB_HIP(hipMemsetAsync(max_key, 0, sizeof(unsigned) * fc, ctx->stream));
         VSTAB_HIP(hipMemsetAsync(cand_count, 0, sizeof(int) * fc, ctx->stream));
-        const dim3 grid((unsigned)((w + ROW_T - 1) / ROW_T), (unsigned)h, (unsigned)fc);
-        hipLaunchKernelGGL(eig_rows_kernel, grid, dim3(ROW_T), 0, ctx->stream, gray + (size_t)f0 * px, h, w, block_size, s, rows, plane);
-        hipLaunchKernelGGL(eig_cols_kernel, grid, dim3(ROW_T), 0, ctx->stream, rows, plane, h, w, block_size, eig, max_key);
-        hipLaunchKernelGGL(corner_collect_kernel, grid, dim3(ROW_T), 0, ctx->stream, eig, max_key, h, w, quality, keys, cap, cand_count);
+        {
+            const int ext = EIG_TILE + block_size - 1;
+            const size_t lds = (((size_t)3 * ext * ext * sizeof(float) + 15) & ~size_t(15)) + (size_t)3 * ext * EIG_TILE * sizeof(double);
+            if (lds > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eig_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const dim3 tgrid((unsigned)((w + EIG_TILE - 1) / EIG_TILE), (unsigned)((h + EIG_TILE - 1) / EIG_TILE), (unsigned)fc);
+            hipLaunchKernelGGL(eig_tile_kernel, tgrid, dim3(EIG_T), lds, ctx->stream, gray + (size_t)f0 * px, h, w, block_size, s, eig, max_key);
+        }
+        if (h > 2 && w > 2) {
+            const dim3 cgrid((unsigned)(h - 2), (unsigned)fc);
+            hipLaunchKernelGGL((corner_collect_kernel<false>), cgrid, dim3(ROW_T), 0, ctx->stream, eig, max_key, h, w, quality, keys, cap, row_count);
+            hipLaunchKernelGGL(corner_scan_kernel, dim3((unsigned)fc), dim3(256), 0, ctx->stream, row_count, h, cand_count);
+            hipLaunchKernelGGL((corner_collect_kernel<true>), cgrid, dim3(ROW_T), 0, ctx->stream, eig, max_key, h, w, quality, keys, cap, row_count);
+        }
         hipLaunchKernelGGL(corner_select_kernel, dim3((unsigned)fc), dim3(SEL_T), 0, ctx->stream, keys, cap, cand_count, w, max_corners,
                            (float)(min_distance * min_distance), min_distance >= 1.0 ? 1 : 0, corners + (size_t)f0 * max_corners * 2, counts + f0);
         VSTAB_HIP(hipGetLastError());
