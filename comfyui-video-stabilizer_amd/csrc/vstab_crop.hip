@@ -46,35 +46,63 @@ __global__ __launch_bounds__(256) void coverage_kernel(const CovXform* __restric
     }
 }
 
-// closing (dilate 3x3 then erode 3x3, out-of-image pixels ignored by both) + per-frame bounding box
-__global__ __launch_bounds__(256) void close_bbox_kernel(const uint8_t* __restrict__ cov, int* __restrict__ bbox, int n, int dh, int dw)
+// closing = dilate 3x3 then erode 3x3 (out-of-image pixels ignored by both), in two passes over u8 planes, and the
+// per-frame bounding box of the result.  One workgroup per (8-row band, frame): the box is reduced in registers,
+// wavefront shuffles and LDS, and reaches memory as 4 atomics per workgroup -- per-pixel atomics on the four words of
+// a frame serialised to a full second per 256 x 1080p clip.
+constexpr int BAND = 8;
+
+__global__ __launch_bounds__(256) void dilate3_kernel(const uint8_t* __restrict__ cov, uint8_t* __restrict__ dil, int dh, int dw)
 {
-    const long long total = (long long)n * dh * dw;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(t % dw);
-        const long long r = t / dw;
-        const int y = (int)(r % dh);
-        const int f = (int)(r / dh);
-        const uint8_t* C = cov + (size_t)f * dh * dw;
-        int eroded = 1;
-        for (int ey = -1; ey <= 1 && eroded; ey++)
-            for (int ex = -1; ex <= 1 && eroded; ex++) {
+    const int f = blockIdx.y, y0 = blockIdx.x * BAND;
+    const uint8_t* C = cov + (size_t)f * dh * dw;
+    uint8_t* D = dil + (size_t)f * dh * dw;
+    for (int k = threadIdx.x; k < BAND * dw; k += 256) {
+        const int y = y0 + k / dw, x = k % dw;
+        if (y >= dh) break;
+        int v = 0;
+        for (int gy = -1; gy <= 1; gy++)
+            for (int gx = -1; gx <= 1; gx++) {
+                const int py = y + gy, px = x + gx;
+                if (py < 0 || py >= dh || px < 0 || px >= dw) continue;   // dilate border = -inf
+                v |= C[(size_t)py * dw + px];
+            }
+        D[(size_t)y * dw + x] = (uint8_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void erode_bbox_kernel(const uint8_t* __restrict__ dil, int* __restrict__ bbox, int dh, int dw)
+{
+    __shared__ int s_box[4][4];
+    const int f = blockIdx.y, y0 = blockIdx.x * BAND;
+    const uint8_t* D = dil + (size_t)f * dh * dw;
+    int x_lo = 0x7fffffff, y_lo = 0x7fffffff, x_hi = -1, y_hi = -1;
+    for (int k = threadIdx.x; k < BAND * dw; k += 256) {
+        const int y = y0 + k / dw, x = k % dw;
+        if (y >= dh) break;
+        int v = 1;
+        for (int ey = -1; ey <= 1; ey++)
+            for (int ex = -1; ex <= 1; ex++) {
                 const int qy = y + ey, qx = x + ex;
                 if (qy < 0 || qy >= dh || qx < 0 || qx >= dw) continue;   // erode border = +inf
-                int dil = 0;
-                for (int gy = -1; gy <= 1 && !dil; gy++)
-                    for (int gx = -1; gx <= 1 && !dil; gx++) {
-                        const int py = qy + gy, px = qx + gx;
-                        if (py < 0 || py >= dh || px < 0 || px >= dw) continue;   // dilate border = -inf
-                        dil |= C[(size_t)py * dw + px];
-                    }
-                eroded &= dil;
+                v &= D[(size_t)qy * dw + qx];
             }
-        if (eroded) {
-            atomicMin(bbox + f * 4 + 0, x);
-            atomicMin(bbox + f * 4 + 1, y);
-            atomicMax(bbox + f * 4 + 2, x);
-            atomicMax(bbox + f * 4 + 3, y);
+        if (v) { x_lo = min(x_lo, x); y_lo = min(y_lo, y); x_hi = max(x_hi, x); y_hi = max(y_hi, y); }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        x_lo = min(x_lo, __shfl_down(x_lo, sft)); y_lo = min(y_lo, __shfl_down(y_lo, sft));
+        x_hi = max(x_hi, __shfl_down(x_hi, sft)); y_hi = max(y_hi, __shfl_down(y_hi, sft));
+    }
+    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = x_lo; b[1] = y_lo; b[2] = x_hi; b[3] = y_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) {
+            x_lo = min(x_lo, s_box[i][0]); y_lo = min(y_lo, s_box[i][1]); x_hi = max(x_hi, s_box[i][2]); y_hi = max(y_hi, s_box[i][3]);
+        }
+        if (x_hi >= 0) {
+            atomicMin(bbox + f * 4 + 0, x_lo); atomicMin(bbox + f * 4 + 1, y_lo);
+            atomicMax(bbox + f * 4 + 2, x_hi); atomicMax(bbox + f * 4 + 3, y_hi);
         }
     }
 }
@@ -135,12 +163,13 @@ extern "C" int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n,
     void* d_xf = nullptr;
     if (vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(CovXform), &d_xf)) return 1;
     const size_t npx = (size_t)out_h * out_w;
-    const size_t need = (size_t)n * npx + 2 * npx + sizeof(int) * 4 * (size_t)n + 1024;
+    const size_t need = 2 * (size_t)n * npx + 2 * npx + sizeof(int) * 4 * (size_t)n + 1024;
     if (ctx->d_gray_tmp.reserve(need)) return 1;
     const size_t npx_al = (npx + 15) & ~size_t(15);
     if (ctx->h_fit.reserve(npx_al + sizeof(int) * 4 * (size_t)n)) return 1;
     uint8_t* d_cov = static_cast<uint8_t*>(ctx->d_gray_tmp.ptr);
-    uint8_t* d_common = d_cov + (size_t)n * npx;
+    uint8_t* d_dil = d_cov + (size_t)n * npx;
+    uint8_t* d_common = d_dil + (size_t)n * npx;
     uint8_t* d_eroded = d_common + npx;
     int* d_bbox = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(d_eroded + npx) + 255) & ~uintptr_t(255));
     std::vector<int> init((size_t)n * 4);
@@ -154,7 +183,11 @@ extern "C" int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n,
     const long long items = (long long)n * out_h * out_w;
     hipLaunchKernelGGL(coverage_kernel, dim3(grid_for(items)), dim3(256), 0, st, static_cast<const CovXform*>(d_xf), d_cov, n, src_h, src_w,
                        out_h, out_w, bw0);
-    hipLaunchKernelGGL(close_bbox_kernel, dim3(grid_for(items)), dim3(256), 0, st, d_cov, d_bbox, n, out_h, out_w);
+    {
+        const dim3 bgrid((unsigned)((out_h + BAND - 1) / BAND), (unsigned)n);
+        hipLaunchKernelGGL(dilate3_kernel, bgrid, dim3(256), 0, st, d_cov, d_dil, out_h, out_w);
+        hipLaunchKernelGGL(erode_bbox_kernel, bgrid, dim3(256), 0, st, d_dil, d_bbox, out_h, out_w);
+    }
     hipLaunchKernelGGL(common_kernel, dim3(grid_for((long long)npx)), dim3(256), 0, st, d_cov, d_common, n, (int)npx);
     hipLaunchKernelGGL(erode3_kernel, dim3(grid_for((long long)npx)), dim3(256), 0, st, d_common, d_eroded, out_h, out_w);
     VSTAB_HIP(hipGetLastError());
