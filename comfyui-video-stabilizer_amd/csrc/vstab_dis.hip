@@ -18,6 +18,7 @@
 //     [P, h, w]; the working set at the finest level (240x135) is L2/Infinity-Cache resident
 //   * nothing here is a contraction: no MFMA
 #include "vstab_internal.h"
+#include <cstdlib>
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
@@ -447,6 +448,184 @@ __global__ __launch_bounds__(256 * PIS_ROW_WAVES) __attribute__((amdgpu_num_sgpr
 #endif
     __syncthreads();
     // this block's stripes only
+    const int blk_lo = min(half * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
+    const int blk_hi = min((half + 1) * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
+    float* Sx = a.Sx + (size_t)pair * hs * ws;
+    float* Sy = a.Sy + (size_t)pair * hs * ws;
+    for (int k = blk_lo * ws + threadIdx.x; k < blk_hi * ws; k += blockDim.x) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
+}
+
+// ---- patch inverse search, two patch rows per wavefront ----------------------------------------
+// Same algorithm and the same arithmetic as pis_kernel, other mapping: a wavefront holds TWO 8x8 patches (lanes
+// 0-31 and 32-63, two horizontally adjacent pixels per lane) of two consecutive patch rows of a stripe; the second
+// row trails the first by one patch, which is exactly the raster dependency (left neighbour = own previous patch,
+// vertical neighbour = the other half's previous patch).  The weight / update arithmetic that is uniform over a
+// patch is issued once for both patches, so the VALU work per patch -- the bound of pis_kernel -- nearly halves;
+// half as many wavefronts carry the same chains.  The 64-pixel sums keep the butterfly association of wave_sum():
+// in-lane pair, quad_perm x2 (columns), row_half_mirror, row_mirror, row_bcast15 (rows), every level adding the same
+// two partial sums, so the totals (lane 31 / lane 63 of the halves) are bit-identical.
+
+__device__ __forceinline__ float half_sum(float v0, float v1, int bperm_addr)
+{
+    float v = v0 + v1;
+    v += dpp_fetch<0xB1, 0xf>(v);
+    v += dpp_fetch<0x4E, 0xf>(v);
+    v += dpp_fetch<0x141, 0xf>(v);
+    v += dpp_fetch<0x140, 0xf>(v);
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm_addr, __builtin_bit_cast(int, v)));
+}
+
+// PIS2_PAIR_WAVES wavefronts per stripe share its row pairs round-robin (2 where a stripe has 3-4 rows, 1 for 2 rows).
+template <int PIS2_PAIR_WAVES>
+__global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void pis2_kernel(PisArgs a)
+{
+    extern __shared__ unsigned char pis_lds[];
+    const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int H = lane >> 5, hl = lane & 31, r = hl >> 2, c2 = hl & 3;
+    const int stripe = half * PIS_STRIPES_PER_BLOCK + wave / PIS2_PAIR_WAVES, pw = wave % PIS2_PAIR_WAVES;
+    const int w = a.w, h = a.h, ws = a.ws, hs = a.hs;
+    const int w_ext = w + 2 * DIS_BORDER, h_ext = h + 2 * DIS_BORDER;
+    const int img_bytes = (w_ext * h_ext + 15) & ~15;
+    unsigned char* lI1 = pis_lds;
+    float* lSx = reinterpret_cast<float*>(pis_lds + img_bytes);
+    float* lSy = lSx + hs * ws;
+    int* done0 = reinterpret_cast<int*>(lSy + hs * ws);
+    int* done1 = done0 + hs;
+    {
+        const unsigned char* sb = a.Iext + (size_t)(pair + 1) * h_ext * w_ext;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(sb) & 15) == 0);
+        const int nvec = aligned ? (w_ext * h_ext) / 16 : 0;
+        const uint4* src = reinterpret_cast<const uint4*>(sb);
+        uint4* dst = reinterpret_cast<uint4*>(lI1);
+        for (int k = threadIdx.x; k < nvec; k += blockDim.x) dst[k] = src[k];
+        for (int k = nvec * 16 + threadIdx.x; k < w_ext * h_ext; k += blockDim.x) lI1[k] = sb[k];
+        for (int k = threadIdx.x; k < 2 * hs; k += blockDim.x) done0[k] = 0;
+    }
+    __syncthreads();
+    const int row_lo = min(stripe * a.stripe_sz, hs), row_hi = min((stripe + 1) * a.stripe_sz, hs);
+    const int nrows = row_hi - row_lo, npairs = (nrows + 1) >> 1;
+    const uint8_t* I0 = a.I + (size_t)pair * h * w;
+    const short* Ix = a.Ix + (size_t)pair * h * w;
+    const short* Iy = a.Iy + (size_t)pair * h * w;
+    const size_t tplane = (size_t)a.n * hs * ws;
+    const float* T = a.tensor + (size_t)pair * hs * ws;
+    const float* U = a.U + (size_t)pair * h * w;
+    const float* V = a.V + (size_t)pair * h * w;
+    const float i_lo = DIS_BORDER - PSZ + 1.0f, i_hi = DIS_BORDER + h - 1.0f;
+    const float j_lo = DIS_BORDER - PSZ + 1.0f, j_hi = DIS_BORDER + w - 1.0f;
+    const int num_inner_iter = GD_ITERS / 2;
+    const float nn = (float)(PSZ * PSZ);
+    const int lane_off2 = r * w_ext + 2 * c2;
+    const int bperm = ((lane & 32) | 31) << 2;
+
+    for (int iter = 0; iter < 2; iter++) {
+        const int dir = (iter == 0) ? 1 : -1;
+        const int start_is = (iter == 0) ? row_lo : row_hi - 1;
+        const int start_js = (iter == 0) ? 0 : ws - 1;
+        volatile int* done = (iter == 0) ? done0 : done1;
+        for (int k = pw; k < npairs; k += PIS2_PAIR_WAVES) {
+            const int row_a = start_is + dir * 2 * k;                 // leading row of the pair in this pass
+            const bool b_valid = 2 * k + 1 < nrows;
+            const int is = row_a + dir * H;
+            const bool row_ok = (H == 0) || b_valid;
+            const int i = is * PSTR;
+            if (iter == 1) {
+                // the backward pass starts from this row's forward-pass result; the pairing (hence the wavefront that
+                // produced it) may differ between the passes, so wait for the forward pass of both rows
+                wait_progress(done0 + row_a, ws);
+                if (b_valid) wait_progress(done0 + (row_a + dir), ws);
+            }
+            for (int s = 0; s <= ws; s++) {
+                const int visited = s - H;                             // patches this half finished before this step
+                const bool act = row_ok && visited >= 0 && visited < ws;
+                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1);   // leading row's vertical neighbour (other wave)
+                if (act) {
+                    const int js = start_js + dir * visited;
+                    const int j = js * PSTR;
+                    const int sidx = is * ws + js;
+                    const size_t poff = (size_t)(i + r) * w + j + 2 * c2;
+                    const float i0a = (float)I0[poff], i0b = (float)I0[poff + 1];
+                    const float gxa = (float)Ix[poff], gxb = (float)Ix[poff + 1];
+                    const float gya = (float)Iy[poff], gyb = (float)Iy[poff + 1];
+                    const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
+                    const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
+                    float Sxv, Syv;
+                    if (iter == 0) {
+                        Sxv = U[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
+                        Syv = V[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
+                    } else {
+                        Sxv = lSx[sidx];
+                        Syv = lSy[sidx];
+                    }
+#define PATCH_DIFF2(bw, d0_, d1_)                                                                          \
+    do {                                                                                                   \
+        const unsigned char* q_ = lI1 + (bw).off + lane_off2;                                              \
+        const float q00_ = (float)q_[0], q01_ = (float)q_[1], q02_ = (float)q_[2];                         \
+        const float q10_ = (float)q_[w_ext], q11_ = (float)q_[w_ext + 1], q12_ = (float)q_[w_ext + 2];     \
+        d0_ = (bw).w00 * q00_ + (bw).w01 * q01_ + (bw).w10 * q10_ + (bw).w11 * q11_ - i0a;                 \
+        d1_ = (bw).w00 * q01_ + (bw).w01 * q02_ + (bw).w10 * q11_ + (bw).w11 * q12_ - i0b;                 \
+    } while (0)
+#define SSD_AT2(dst, ux, uy)                                                                               \
+    do {                                                                                                   \
+        Bilin b_ = bilin_weights(i, j, (ux), (uy), i_lo, i_hi, j_lo, j_hi, w_ext);                         \
+        float e0_, e1_;                                                                                    \
+        PATCH_DIFF2(b_, e0_, e1_);                                                                         \
+        const float sd_ = half_sum(e0_, e1_, bperm), sq_ = half_sum(e0_ * e0_, e1_ * e1_, bperm);          \
+        dst = sq_ - sd_ * sd_ / nn;                                                                        \
+    } while (0)
+                    float min_SSD, cur_SSD;
+                    SSD_AT2(min_SSD, Sxv, Syv);
+                    if (visited > 0) {
+                        const float nx = lSx[sidx - dir], ny = lSy[sidx - dir];
+                        SSD_AT2(cur_SSD, nx, ny);
+                        if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
+                    }
+                    if (H == 1 || k > 0) {                              // a previously visited row exists in this pass
+                        const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
+                        SSD_AT2(cur_SSD, nx, ny);
+                        if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
+                    }
+                    float cur_Ux = Sxv, cur_Uy = Syv;
+                    float detH = txx * tyy - txy * txy;
+                    if (__builtin_fabsf(detH) < DIS_EPS) detH = DIS_EPS;
+                    const float invH11 = tyy / detH, invH12 = -txy / detH, invH22 = txx / detH;
+                    float prev_SSD = DIS_INF;
+                    for (int t = 0; t < num_inner_iter; t++) {
+                        Bilin b = bilin_weights(i, j, cur_Ux, cur_Uy, i_lo, i_hi, j_lo, j_hi, w_ext);
+                        float d0, d1;
+                        PATCH_DIFF2(b, d0, d1);
+                        const float sum_diff = half_sum(d0, d1, bperm), sum_sq = half_sum(d0 * d0, d1 * d1, bperm);
+                        const float sum_x = half_sum(d0 * gxa, d1 * gxb, bperm), sum_y = half_sum(d0 * gya, d1 * gyb, bperm);
+                        const float dUx = sum_x - sum_diff * x_grad_sum / nn;
+                        const float dUy = sum_y - sum_diff * y_grad_sum / nn;
+                        const float SSD = sum_sq - sum_diff * sum_diff / nn;
+                        const float dx = invH11 * dUx + invH12 * dUy;
+                        const float dy = invH12 * dUx + invH22 * dUy;
+                        cur_Ux -= dx;
+                        cur_Uy -= dy;
+                        if (SSD >= prev_SSD) break;
+                        prev_SSD = SSD;
+                    }
+#undef SSD_AT2
+#undef PATCH_DIFF2
+                    {
+                        const double ddx = (double)(cur_Ux - Sxv), ddy = (double)(cur_Uy - Syv);
+                        if (__builtin_sqrt(ddx * ddx + ddy * ddy) <= (double)PSZ) { Sxv = cur_Ux; Syv = cur_Uy; }
+                    }
+                    if (hl == 0) {
+                        lSx[sidx] = Sxv;
+                        lSy[sidx] = Syv;
+                        __hip_atomic_store(const_cast<int*>(done + is), visited + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
     const int blk_lo = min(half * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
     const int blk_hi = min((half + 1) * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
     float* Sx = a.Sx + (size_t)pair * hs * ws;
@@ -1002,7 +1181,16 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
         // rows of a stripe are pipelined over 4 waves only where a stripe has enough rows to pay for it
-        if (pa.stripe_sz >= 3) {
+        static const bool use_pis2 = !(getenv("VSTAB_PIS2") && atoi(getenv("VSTAB_PIS2")) == 0);
+        if (pa.stripe_sz >= 3 && use_pis2) {
+            if (lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis2_kernel<2>, dim3((unsigned)P * 2), dim3(64 * 2 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
+        } else if (pa.stripe_sz == 2 && use_pis2) {
+            if (lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis2_kernel<1>, dim3((unsigned)P * 2), dim3(64 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
+        } else if (pa.stripe_sz >= 3) {
             if (lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL(pis_kernel<4>, dim3((unsigned)P * 2), dim3(1024), lds_bytes, st, pa);
