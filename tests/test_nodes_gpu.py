@@ -288,3 +288,17 @@ def test_reference_script_scenarios_on_tiny_clip(api, ctx, oracle, framing, mode
     ref, ref_mask, _ = oracle.warp_clip(frames, fm, out_size, border=BORDER)
     assert np.array_equal(res.frames, ref) and np.array_equal(res.masks[..., 0], ref_mask)
     assert res.meta["fps_effective"] == 24.0
+
+
+def test_pinned_output_option_is_transparent(api, ctx, monkeypatch):
+    """VSTAB_PINNED_OUTPUT=1 only changes where the returned CPU tensors live (page-locked memory, one direct DMA):
+    same values, same shapes, still CPU tensors."""
+    import torch
+
+    frames = torch.from_numpy(synth_frames(4, 72, 128))
+    args = (frames, 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    plain = api.nodes.VideoStabilizerFlow.execute(*args)
+    monkeypatch.setenv("VSTAB_PINNED_OUTPUT", "1")
+    pinned = api.nodes.VideoStabilizerFlow.execute(*args)
+    assert pinned[0].device.type == "cpu" and pinned[0].is_pinned() and pinned[1].is_pinned() and not plain[0].is_pinned()
+    assert torch.equal(plain[0], pinned[0]) and torch.equal(plain[1], pinned[1]) and plain[2] == pinned[2]
