@@ -778,12 +778,13 @@ struct LevelArgs {
 };
 
 constexpr int SOR_HALO = 2 * SOR_ITERS;   // one pixel of dependency per half-sweep
-// Tuned on MI355X (profiles/r01_fused_tile_sweep.md): with 16 waves per CU a wave has 128 VGPRs; 4 or 5 owned
-// pixels per colour spill (the per-pixel LDS addresses are hoisted out of the sweep loop next to the
-// coefficients), and the spills cost more than the extra halo work of smaller tiles.
+// Tuned on MI355X (profiles/r01_fused_tile_sweep.md): with 16 waves per CU a wave has 128 VGPRs.  With the tile in
+// three separate LDS planes 4 or 5 owned pixels per colour spilled (nine loop-invariant LDS addresses per pixel
+// next to the coefficients) and 3 was fastest; with the interleaved float4 tile (three addresses per pixel) 5 fit
+// without spilling, and the larger tiles (less halo work) win: 5 is also the LDS limit (160 KB / 16 B per pixel).
 #ifndef VSTAB_FUSED_T
 #define VSTAB_FUSED_T 1024
-#define VSTAB_SOR_NPT 3
+#define VSTAB_SOR_NPT 5
 #endif
 constexpr int FUSED_T = VSTAB_FUSED_T;    // threads of the fused level kernel
 constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour (tile <= 2 * SOR_NPT * FUSED_T px)
@@ -834,9 +835,14 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
     const float* __restrict__ pIz = b.Iz + base;   const float* __restrict__ pIxx = b.Ixx + base;
     const float* __restrict__ pIxy = b.Ixy + base; const float* __restrict__ pIyy = b.Iyy + base;
     const float* __restrict__ pIxz = b.Ixz + base; const float* __restrict__ pIyz = b.Iyz + base;
-    float* lW = vr_lds;                    // smoothness weights
-    float* lU = vr_lds + a.lds_plane;      // dU
-    float* lV = vr_lds + 2 * a.lds_plane;  // dV
+    // LDS tile: one float4 (dU, dV, smoothness weight, pad) per padded pixel -- an update reads its own and its
+    // left / up neighbours' triples with one 16-B load each and the right / down increments with one 8-B load each
+    // (6 LDS instructions instead of 15), and only three loop-invariant addresses per owned pixel are live in the
+    // sweep loop instead of nine (three planes x own / up / down), which is what lets a thread own more pixels
+    // without spilling.
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f4_t* lP = reinterpret_cast<f4_t*>(vr_lds);
     // increment ping-pong: (dU,dV) <-> (tU,tV) planes of the workspace
     float* dIn_u = b.dU + base;  float* dIn_v = b.dV + base;
     float* dOut_u = b.tU + base; float* dOut_v = b.tV + base;
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                     const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
                     wv = a.alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2);
                 }
-                lW[k] = wv; lU[k] = du; lV[k] = dv;
+                lP[k] = f4_t{du, dv, wv, 0.f};
             }
             __syncthreads();
             FUSED_MARK(3);
@@ -898,7 +904,8 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                             const unsigned uq_ = (unsigned)q;   // uniform (SGPR) plane base + 32-bit lane offset
                             const float Ix = pIx[uq_], Iy = pIy[uq_], Iz = pIz[uq_], Ixx = pIxx[uq_], Ixy = pIxy[uq_], Iyy = pIyy[uq_],
                                         Ixz = pIxz[uq_], Iyz = pIyz[uq_];
-                            const float du = lU[li], dv = lV[li];
+                            const f4_t own = lP[li];
+                            const float du = own.x, dv = own.y;
                             float a11, a12, a22, B1, B2;
                             {
                                 float derivNorm = Ix * Ix + Iy * Iy + a.zeta2;
@@ -923,11 +930,11 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                             // smoothness term, accumulated in OpenCV's red/black scatter order.  `color` IS the global
                             // checkerboard parity (gx + gy) & 1 of the pixel, so the order is known at compile time.
                             const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
-                            const float wq = lW[li], uq = U[q], vq = V[q];
+                            const float wq = own.z, uq = U[q], vq = V[q];
 #define SM_RIGHT() if (has_r) { B1 += wq * (U[q + 1] - uq); a11 += wq; B2 += wq * (V[q + 1] - vq); a22 += wq; }
-#define SM_LEFT()  if (has_l) { const float wl = lW[li - 1]; B1 -= wl * (uq - U[q - 1]); a11 += wl; B2 -= wl * (vq - V[q - 1]); a22 += wl; }
+#define SM_LEFT()  if (has_l) { const float wl = lP[li - 1].z; B1 -= wl * (uq - U[q - 1]); a11 += wl; B2 -= wl * (vq - V[q - 1]); a22 += wl; }
 #define SM_DOWN()  if (has_d) { B1 += wq * (U[q + w] - uq); a11 += wq; B2 += wq * (V[q + w] - vq); a22 += wq; }
-#define SM_UP()    if (has_u) { const float wu = lW[li - pw]; B1 -= wu * (uq - U[q - w]); a11 += wu; B2 -= wu * (vq - V[q - w]); a22 += wu; }
+#define SM_UP()    if (has_u) { const float wu = lP[li - pw].z; B1 -= wu * (uq - U[q - w]); a11 += wu; B2 -= wu * (vq - V[q - w]); a22 += wu; }
                             if (color == 0) { SM_RIGHT() SM_LEFT() SM_DOWN() SM_UP() }
                             else            { SM_LEFT() SM_RIGHT() SM_UP() SM_DOWN() }
 #undef SM_RIGHT
@@ -963,14 +970,15 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                     for (int u = 0; u < SOR_NPT; u++) {
                         const int li = cidx[color][u];
                         if (li >= 0) {
-                            const float wq = lW[li], wl = lW[li - 1], wu = lW[li - pw];
-                            const float sigmaU = wl * lU[li - 1] + wq * lU[li + 1] + wu * lU[li - pw] + wq * lU[li + pw];
-                            const float sigmaV = wl * lV[li - 1] + wq * lV[li + 1] + wu * lV[li - pw] + wq * lV[li + pw];
-                            float du = lU[li], dv = lV[li];
+                            const f4_t pc = lP[li], pl = lP[li - 1], pu = lP[li - pw];
+                            const f2_t pr = *reinterpret_cast<const f2_t*>(lP + li + 1), pd = *reinterpret_cast<const f2_t*>(lP + li + pw);
+                            const float wq = pc.z, wl = pl.z, wu = pu.z;
+                            const float sigmaU = wl * pl.x + wq * pr.x + wu * pu.x + wq * pd.x;
+                            const float sigmaV = wl * pl.y + wq * pr.y + wu * pu.y + wq * pd.y;
+                            float du = pc.x, dv = pc.y;
                             du += a.omega * ((sigmaU + cb1[color][u] - dv * c12[color][u]) / c11[color][u] - du);
                             dv += a.omega * ((sigmaV + cb2[color][u] - du * c12[color][u]) / c22[color][u] - dv);
-                            lU[li] = du;
-                            lV[li] = dv;
+                            *reinterpret_cast<f2_t*>(lP + li) = f2_t{du, dv};
                         }
                         __builtin_amdgcn_sched_barrier(0);   // keep the owned pixels' updates apart (register pressure)
                     }
@@ -984,8 +992,9 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                 const int yy = k / iw, xx = k - yy * iw;
                 const int gx = ix0 + xx, gy = iy0 + yy;
                 const int li = (gy - oy + 1) * pw + (gx - ox + 1);
-                dOut_u[gy * w + gx] = lU[li];
-                dOut_v[gy * w + gx] = lV[li];
+                const f2_t uv = *reinterpret_cast<const f2_t*>(lP + li);
+                dOut_u[gy * w + gx] = uv.x;
+                dOut_v[gy * w + gx] = uv.y;
             }
             __syncthreads();
             FUSED_MARK(6);
@@ -1219,13 +1228,13 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
                 return ((lw + 1) / 2) * lh;   // pixels of one colour
             };
             int padded = 0;
-            while (tile_px(tx, ty, padded) > SOR_NPT * FUSED_T) {
+            while (tile_px(tx, ty, padded) > SOR_NPT * FUSED_T || (size_t)padded * 16 > 160 * 1024) {   // registers and LDS
                 if ((g.w + tx - 1) / tx >= (g.h + ty - 1) / ty) tx++; else ty++;
                 VSTAB_REQUIRE(tx <= 64 && ty <= 64, "vstab_dis_flow_batch: cannot tile a %dx%d level", g.w, g.h);
             }
             la.tiles_x = tx; la.tiles_y = ty; la.lds_plane = (padded + 3) & ~3;
         }
-        const size_t vr_lds_bytes = sizeof(float) * 3 * (size_t)la.lds_plane;
+        const size_t vr_lds_bytes = sizeof(float) * 4 * (size_t)la.lds_plane;
         VSTAB_REQUIRE(vr_lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: SOR tile needs %zu B of LDS", vr_lds_bytes);
         if (vr_lds_bytes > 64 * 1024)
             VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
