@@ -141,7 +141,9 @@ FLOW_META_KEYS = ["frames", "transform_mode_requested", "transform_mode_applied"
 
 @pytest.mark.parametrize("size,mode,framing", [((480, 270), "similarity", "crop_and_pad"), ((480, 270), "translation", "expand"),
                                                ((1920, 1080), "similarity", "crop_and_pad"),
-                                               ((480, 270), "perspective", "crop_and_pad")])
+                                               ((480, 270), "perspective", "crop_and_pad"),
+                                               ((1000, 777), "similarity", "expand"),        # non-integer area ratio 960x746
+                                               ((720, 1280), "similarity", "crop_and_pad")])  # portrait, working size 540x960
 def test_flow_pipeline_against_oracle(api, ctx, oracle, size, mode, framing):
     """Every stage of the Flow node vs the oracle on a clip with known motion; KA7 replay bit-identity;
     the meta key set / list lengths / types of SURVEY 8a "Meta detail"."""
