@@ -17,6 +17,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
+    """The package under its import alias; on a fresh checkout (built artefacts are git-ignored) the native library
+    and the oracle are compiled first -- hipcc cross-compiles without a GPU, ~25 s."""
+    lib = ROOT / "comfyui-video-stabilizer_amd" / "lib" / "libvstab.so"
+    if not lib.exists():
+        graft.build()
     return graft.load_package()
 
 
