@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256 * PIS_ROW_WAVES) __attribute__((amdgpu_num_sgpr
 // in-lane pair, quad_perm x2 (columns), row_half_mirror, row_mirror, row_bcast15 (rows), every level adding the same
 // two partial sums, so the totals (lane 31 / lane 63 of the halves) are bit-identical.
 
-__device__ __forceinline__ float half_sum(float v0, float v1, int bperm_addr)
+__device__ __forceinline__ float half_sum(float v0, float v1)
 {
     float v = v0 + v1;
     v += dpp_fetch<0xB1, 0xf>(v);
@@ -473,7 +473,11 @@ __device__ __forceinline__ float half_sum(float v0, float v1, int bperm_addr)
     v += dpp_fetch<0x141, 0xf>(v);
     v += dpp_fetch<0x140, 0xf>(v);
     asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm_addr, __builtin_bit_cast(int, v)));
+    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU
+    // instructions on the critical path of the gradient descent; a ds_bpermute is an LDS round trip
+    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return (__lane_id() & 32) ? t1 : t0;
 }
 
 // PIS2_PAIR_WAVES wavefronts per stripe share its row pairs round-robin (2 where a stripe has 3-4 rows, 1 for 2 rows).
@@ -518,7 +522,6 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
     const int num_inner_iter = GD_ITERS / 2;
     const float nn = (float)(PSZ * PSZ);
     const int lane_off2 = r * w_ext + 2 * c2;
-    const int bperm = ((lane & 32) | 31) << 2;
 
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
         Bilin b_ = bilin_weights(i, j, (ux), (uy), i_lo, i_hi, j_lo, j_hi, w_ext);                         \
         float e0_, e1_;                                                                                    \
         PATCH_DIFF2(b_, e0_, e1_);                                                                         \
-        const float sd_ = half_sum(e0_, e1_, bperm), sq_ = half_sum(e0_ * e0_, e1_ * e1_, bperm);          \
+        const float sd_ = half_sum(e0_, e1_), sq_ = half_sum(e0_ * e0_, e1_ * e1_);          \
         dst = sq_ - sd_ * sd_ / nn;                                                                        \
     } while (0)
                     float min_SSD, cur_SSD;
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                         Bilin b = bilin_weights(i, j, cur_Ux, cur_Uy, i_lo, i_hi, j_lo, j_hi, w_ext);
                         float d0, d1;
                         PATCH_DIFF2(b, d0, d1);
-                        const float sum_diff = half_sum(d0, d1, bperm), sum_sq = half_sum(d0 * d0, d1 * d1, bperm);
-                        const float sum_x = half_sum(d0 * gxa, d1 * gxb, bperm), sum_y = half_sum(d0 * gya, d1 * gyb, bperm);
+                        const float sum_diff = half_sum(d0, d1), sum_sq = half_sum(d0 * d0, d1 * d1);
+                        const float sum_x = half_sum(d0 * gxa, d1 * gxb), sum_y = half_sum(d0 * gya, d1 * gyb);
                         const float dUx = sum_x - sum_diff * x_grad_sum / nn;
                         const float dUy = sum_y - sum_diff * y_grad_sum / nn;
                         const float SSD = sum_sq - sum_diff * sum_diff / nn;
