@@ -87,7 +87,7 @@ __device__ __forceinline__ Px load_px(const float* p)
 
 template <int INTERP>
 __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int sw, int X, int Y,
-                                        float b0, float b1, float b2)
+                                        float b0, float b1, float b2, const float* cub_tab /* LDS [32][4] or nullptr */)
 {
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const int fx = X & 31, fy = Y & 31;
@@ -123,8 +123,15 @@ __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int
         return o;
     } else {
         float cx[4], cy[4];
-        cubic_coeffs(fx, cx);
-        cubic_coeffs(fy, cy);
+        if (cub_tab != nullptr) {   // OpenCV reads these from its own 32-entry table too (initInterTab1D): same values
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            const f4_t tx = reinterpret_cast<const f4_t*>(cub_tab)[fx], ty = reinterpret_cast<const f4_t*>(cub_tab)[fy];
+            cx[0] = tx.x; cx[1] = tx.y; cx[2] = tx.z; cx[3] = tx.w;
+            cy[0] = ty.x; cy[1] = ty.y; cy[2] = ty.z; cy[3] = ty.w;
+        } else {
+            cubic_coeffs(fx, cx);
+            cubic_coeffs(fy, cy);
+        }
         const int x0 = sx - 1, y0 = sy - 1;
         const unsigned width1 = (unsigned)(sw - 3 > 0 ? sw - 3 : 0);
         const unsigned height1 = (unsigned)(sh - 3 > 0 ? sh - 3 : 0);
@@ -210,6 +217,13 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 {
     constexpr int TILE_W = TILE_TX * TILE_PX, TILE_H = 256 / TILE_TX;
     __shared__ unsigned s_cnt[4];
+    __shared__ __attribute__((aligned(16))) float s_cub[32 * 4];
+    const float* cub_tab = nullptr;
+    if (INTERP == VSTAB_INTERP_BICUBIC) {
+        if (threadIdx.x < 32) cubic_coeffs((int)threadIdx.x, s_cub + threadIdx.x * 4);
+        __syncthreads();
+        cub_tab = s_cub;
+    }
     const unsigned nblk = gridDim.x;
     const unsigned t = xcd_remap(blockIdx.x, nblk);
     const unsigned tiles_per_frame = (unsigned)a.tiles_x * a.tiles_y;
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
                 const bool small = fast_ok && __builtin_fabs(Xn * xf->wq) < 1.0e6 && __builtin_fabs(Yn * xf->wq) < 1.0e6;
                 if (small) {
                     const int X = round_small(Xn * xf->wq), Y = round_small(Yn * xf->wq);
-                    v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
+                    v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2, cub_tab);
                     if (WITH_MASK) {
                         const int nx = round_small(Xn * xf->wn), ny = round_small(Yn * xf->wn);
                         c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
                     } else {
                         const int X = clamp_round_i32(Xn * Wq);
                         const int Y = clamp_round_i32(Yn * Wq);
-                        v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2);
+                        v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2, cub_tab);
                     }
                     if (WITH_MASK) {
                         const int nx = sat_short(clamp_round_i32(Xn * Wn));
