@@ -7,9 +7,9 @@
 // bit-identical to oracle/vo_warp.c.  Built with -ffp-contract=off: no FMA may be formed.
 //
 // Kernel shape (HBM-bound, 28 B of algorithmic traffic per output pixel):
-//   * one thread = 4 consecutive output pixels of one row -> 3x 16-B RGB stores + 1x 16-B mask store
-//   * one 256-thread block = 128 x 8 output tile; its bilinear source footprint (~129 x 9 px,
-//     14 KB) stays in the CU's L1, vertically adjacent tiles share a source row through L2
+//   * one 256-thread block = 64 x 8 output tile (32 threads along x, 2 pixels per thread strided by 32, so the
+//     lanes of a wavefront cover consecutive pixels: tap loads and stores touch whole cache lines); the bilinear
+//     source footprint of the tile stays in the CU's L1, vertically adjacent tiles share a source row through L2
 //   * blockIdx is remapped so that the 8 XCDs (private L2 each) own contiguous runs of tiles
 //   * padding-pixel count: wave shuffle reduction -> LDS -> one atomic per block, only if non-zero
 #include "vstab_internal.h"
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int TILE_PX = 4;        // pixels per thread along x
+constexpr int TILE_PX = 2;        // pixels per thread along x, strided by the tile width (profiles/r01_warp_tile_sweep.md)
 constexpr int MAX_BLUR_SAMPLES = 33;
 
 struct WarpXform {   // per (frame, sample)
@@ -389,7 +389,7 @@ void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t s
 template <bool BLUR>
 int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t st)
 {
-    // threads along x of the 256-thread tile: 32 (128 x 8 px) by default; VSTAB_WARP_TX = 8|16|64 for sweeps
+    // threads along x of the 256-thread tile: 32 (64 x 8 px) by default; VSTAB_WARP_TX = 8|16|64 for sweeps
     // (profiles/r01_warp_tile_sweep.md)
     int tx = 32;
     if (const char* e = getenv("VSTAB_WARP_TX")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 64) tx = v; }
