@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import host_math as hm
-from .flow_pipeline import (complete_meta, estimate_transitions, estimate_transitions_classic, plan_stabilization,
+from .flow_pipeline import (_ESTIMATORS, complete_meta, resolve_flow_backend, plan_stabilization,
                             prepare_meta)
 
 
@@ -118,7 +118,8 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     working_size = hm._working_estimation_size(width, height)
     from . import native
 
-    estimate = estimate_transitions if estimator == "flow" else estimate_transitions_classic
+    estimator = resolve_flow_backend(estimator)
+    estimate = _ESTIMATORS[estimator]
     local_records = (estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
                      else np.zeros((0, 3), native.FIT_DTYPE))
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)

@@ -15,6 +15,7 @@ The host keeps only what is sequential or scalar in the reference (flow.py:324-3
 from __future__ import annotations
 
 import gc
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -45,11 +46,33 @@ class _gc_paused:
 # The Classic node (nodes/video_stabilizer_classic.py) shares this pipeline; only the estimator and a few
 # meta keys differ: no flow_backend / flow_fallback_reason (classic.py:189-208, 236-250, 336-360, 537-568),
 # no per-transition residual (classic.py:549-557), source "estimated_classic" (classic.py:57-61).
-_META_SOURCE = {"flow": "estimated_flow", "classic": "estimated_classic"}
+#
+# "flow_phase_correlate" is the Flow node running on its fallback estimator (flow.py:90-130).  The reference takes
+# that branch when cv2.DISOpticalFlow cannot be created and cv2.optflow (TV-L1, contrib) is missing; here DIS
+# always exists, so the branch is selected only by VSTAB_FLOW_BACKEND=phase_correlate (see resolve_flow_backend).
+_META_SOURCE = {"flow": "estimated_flow", "flow_phase_correlate": "estimated_flow", "classic": "estimated_classic"}
+_PHASE_REASON = "DIS unavailable (disabled by VSTAB_FLOW_BACKEND); cv2.optflow missing; using phase correlation."
+
+
+def resolve_flow_backend(estimator: str) -> str:
+    """_select_flow_backend (flow.py:90-107) for this build: DIS unless the environment asks for the fallback."""
+    if estimator != "flow":
+        return estimator
+    want = os.environ.get("VSTAB_FLOW_BACKEND", "DIS").strip()
+    if want in ("", "DIS", "dis"):
+        return "flow"
+    if want == "phase_correlate":
+        return "flow_phase_correlate"
+    raise ValueError(f"VSTAB_FLOW_BACKEND={want!r}: expected 'DIS' or 'phase_correlate' (TV-L1 needs opencv-contrib in the "
+                     "reference and is not provided).")
 
 
 def _backend_fields(estimator: str) -> Dict[str, Any]:
-    return {"flow_backend": "DIS", "flow_fallback_reason": None} if estimator == "flow" else {}
+    if estimator == "flow":
+        return {"flow_backend": "DIS", "flow_fallback_reason": None}
+    if estimator == "flow_phase_correlate":
+        return {"flow_backend": "phase_correlate", "flow_fallback_reason": _PHASE_REASON}
+    return {}
 
 
 def _attach_motion_meta(meta: Dict[str, Any], fps: float, estimator: str = "flow") -> Dict[str, Any]:
@@ -130,6 +153,17 @@ def estimate_transitions(ctx, device_frames, working_size, transform_mode: str, 
     return ctx.sample_fit_batch(grid, SAMPLE_STEP, transform_mode)
 
 
+def estimate_transitions_phase(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
+    """Fallback estimator (flow.py:110-130, 325-330): phase correlation of consecutive estimation images.  Every pair
+    is reported as a "translation" fit whatever `transform_mode` asks for; confidence = peak response, residual 0."""
+    gray = ctx.gray_downscale(device_frames, working_size)
+    table, _ = ctx.phase_correlate_batch(gray)
+    return table
+
+
+_ESTIMATORS = {}   # filled below the three estimator functions
+
+
 # classic.py:76-96: cv2.goodFeaturesToTrack / cv2.calcOpticalFlowPyrLK arguments of the Classic node
 CLASSIC_GFTT = dict(max_corners=400, quality=0.01, min_distance=7.0, block_size=21)
 CLASSIC_LK = dict(win=31, max_level=3, max_count=50, epsilon=0.01)
@@ -142,6 +176,10 @@ def estimate_transitions_classic(ctx, device_frames, working_size, transform_mod
     corners, counts = ctx.gftt_batch(gray[:-1], **CLASSIC_GFTT)
     pairs = ctx.lk_track_batch(gray, corners, counts, **CLASSIC_LK)
     return ctx.points_fit_batch(pairs, counts, transform_mode)
+
+
+_ESTIMATORS.update({"flow": estimate_transitions, "flow_phase_correlate": estimate_transitions_phase,
+                    "classic": estimate_transitions_classic})
 
 
 def _fps_fields(context: hm.VideoContext, frame_rate) -> Tuple[float, Optional[float]]:
@@ -358,7 +396,7 @@ def _prepare_meta(plan: FlowPlan) -> Dict[str, Any]:
                 {"index": i, "mode": mode, "confidence": conf, "residual": resid, "matrix": mat}
                 for i, (mode, conf, resid, mat) in enumerate(zip(em["modes"], em["confidences"], em["residuals"],
                                                                  np.asarray(em["matrices"], dtype=np.float32).tolist()))
-            ] if plan.estimator == "flow" else [
+            ] if plan.estimator != "classic" else [
                 {"index": i, "mode": mode, "confidence": conf, "matrix": mat}
                 for i, (mode, conf, mat) in enumerate(zip(em["modes"], em["confidences"],
                                                           np.asarray(em["matrices"], dtype=np.float32).tolist()))
@@ -413,6 +451,7 @@ def _stabilize_frames(
     motion estimator to the Classic node's sparse tracker (classic.py:163-173, same signature)."""
     if estimator not in _META_SOURCE:
         raise ValueError(f"Unknown estimator {estimator!r}; expected 'flow' or 'classic'.")
+    estimator = resolve_flow_backend(estimator)
     total_frames = len(context.frames)
     fps_effective, fps_requested = _fps_fields(context, frame_rate)
     size = (context.width, context.height)
@@ -451,7 +490,7 @@ def _stabilize_frames(
             "note": "Single-frame input; bypassed stabilization.",
             "transform_mode": transform_mode,
             "framing_mode": framing_mode,
-            **({"keep_fov_applied": False} if estimator == "flow" else {}),   # flow.py:297 only; classic.py:236-250 has no such key
+            **({"keep_fov_applied": False} if estimator != "classic" else {}),   # flow.py:297 only; classic.py:236-250 has no such key
             **_backend_fields(estimator),
             "stabilization_warp": hm._build_stabilization_warp_meta(
                 source_size=size, output_size=size, framing_mode=framing_mode,
@@ -469,7 +508,7 @@ def _stabilize_frames(
     working_size = hm._working_estimation_size(context.width, context.height)
 
     # ---- estimation (F2-F5) -------------------------------------------------
-    estimate = estimate_transitions if estimator == "flow" else estimate_transitions_classic
+    estimate = _ESTIMATORS[estimator]
     fit_records = estimate(ctx, device_frames, working_size, transform_mode)
     progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
     check_interrupt()

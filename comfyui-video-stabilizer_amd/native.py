@@ -127,6 +127,8 @@ _SIGNATURES = {
                   C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_points_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_phase_correlate_batch": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_host_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_crop_analysis": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -404,6 +406,25 @@ class Context:
                                                MODES[requested_mode], table.ctypes.data),
                "vstab_points_fit_batch")
         return table
+
+    # ------------------------------------------------------------------ fallback estimator (phase correlation)
+    def phase_correlate_batch(self, gray):
+        """gray u8 [N,h,w] (device) -> (structured table [N-1,3] (FIT_DTYPE, translation row only),
+        shifts f64 [N-1,3] = (tx, ty, response) of cv2.phaseCorrelate for every consecutive pair)."""
+        if gray.device != self.device:
+            gray = gray.to(self.device)
+        gray = gray.contiguous()
+        if gray.dtype != self.torch.uint8 or gray.dim() != 3:
+            raise ValueError("phase_correlate_batch expects a uint8 [N,h,w] tensor")
+        n, h, w = gray.shape
+        if n < 2:
+            raise ValueError("phase_correlate_batch needs at least two frames")
+        table = np.zeros((n - 1, 3), FIT_DTYPE)
+        shifts = np.zeros((n - 1, 3), np.float64)
+        self.use_torch_stream()
+        _check(self.lib.vstab_phase_correlate_batch(self.handle, _dev_ptr(gray), n, h, w, table.ctypes.data, shifts.ctypes.data),
+               "vstab_phase_correlate_batch")
+        return table, shifts
 
     def crop_analysis(self, matrices, src_size, out_size):
         """Nearest coverage of every frame -> (bbox [n,4] of the 3x3-closed coverage or -1, AND of all frames eroded 3x3)."""

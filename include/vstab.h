@@ -53,7 +53,7 @@ int vstab_destroy(vstab_ctx* ctx);
 int vstab_set_stream(vstab_ctx* ctx, void* hip_stream);
 int vstab_synchronize(vstab_ctx* ctx);
 /* Kernel timing with HIP events recorded on the call's own stream, per kind of call ("warp", "warp_blur",
- * "gray", "dis", "fit", "gftt", "lk").  vstab_set_timing(ctx, 1) enables it and clears the totals.
+ * "gray", "dis", "fit", "gftt", "lk", "phase").  vstab_set_timing(ctx, 1) enables it and clears the totals.
  * vstab_last_kernel_ms: milliseconds of the most recent call of that kind (waits for it to finish).
  * vstab_kernel_ms_stats: sum and number of all calls of that kind since timing was enabled -- no
  * synchronisation is needed inside a timed loop, bench.py reads the totals after its closing fence
@@ -190,6 +190,23 @@ int vstab_lk_track_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int 
                          double epsilon, float* point_pairs, float* next_points, uint8_t* status);
 int vstab_points_fit_batch(vstab_ctx* ctx, const float* point_pairs, const int* counts, int pairs,
                            int max_points, int requested_mode, vstab_fit_record* results);
+
+/* ---- N2 (fallback estimator): phase correlation -------------------------------------
+ * Replaces cv2.phaseCorrelate(prev_gray.astype(float32), curr_gray.astype(float32)) of
+ * nodes/video_stabilizer_flow.py:110-130 (`_estimate_motion_phase_correlate`, the branch of the pair loop
+ * flow.py:325-330 taken when no dense-flow backend could be created, flow.py:90-107) for the n-1 consecutive
+ * pairs of a clip: zero-pad to the optimal DFT size, normalised cross-power spectrum, inverse DFT, first
+ * maximum of the centred correlation surface, 5x5 weighted centroid.
+ *   gray    dev [n,h,w] u8 (estimation images; padded sizes up to 2048)
+ *   results host [pairs*3] records indexed [pair*3 + mode], or NULL: only the translation row is
+ *           computed/accepted (matrix = [1 0 tx; 0 1 ty; 0 0 1], confidence = response, residual 0; a
+ *           non-finite result becomes tx = ty = confidence = 0 as flow.py:115-120 does) -- the reference reports
+ *           every pair of this estimator as "translation" whatever mode was requested
+ *   shifts  host [pairs*3] f64 (tx, ty, response) as cv2.phaseCorrelate returns them, or NULL
+ * Synchronises with the host (results are host values).  Timing kind: "phase".
+ */
+int vstab_phase_correlate_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w,
+                                vstab_fit_record* results, double* shifts);
 
 /* ---- F7 + F8: trajectory (prefix sum, box smoothing, strength blend), fp64 ---
  * Replaces nodes/video_stabilizer_flow.py:356-371 and

@@ -380,6 +380,24 @@ def fit_all_modes_points(prev_pts, next_pts, status, requested_mode="similarity"
     return out, int(nv.value)
 
 
+def optimal_dft_size(n):
+    return int(lib().vo_optimal_dft_size(int(n)))
+
+
+def phase_correlate_clip(gray, want_surface=False):
+    """cv2.phaseCorrelate(gray[i].astype(f32), gray[i+1].astype(f32)) for every consecutive pair (flow.py:110-130)
+    -> shifts f64 [N-1,3] = (tx, ty, response); with want_surface also the unshifted correlation surface of pair 0."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    n, h, w = gray.shape
+    shifts = np.zeros((n - 1, 3), np.float64)
+    surface = np.zeros((optimal_dft_size(h), optimal_dft_size(w)), np.float32) if want_surface else None
+    fn = lib().vo_phase_correlate_clip
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(gray.ctypes.data, n, h, w, shifts.ctypes.data, surface.ctypes.data if want_surface else None)
+    return (shifts, surface) if want_surface else shifts
+
+
 def classic_estimate_pair(prev_gray, curr_gray, requested_mode="similarity"):
     """_estimate_motion_pair (classic.py:69-160): (matrix f32 3x3, used mode, confidence)."""
     feats = good_features(prev_gray, **GFTT)

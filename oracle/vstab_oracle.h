@@ -93,6 +93,12 @@ int vo_lk_levels(int h, int w, int win, int max_level);
 void vo_lk_track(const uint8_t* prev, const uint8_t* next, int h, int w, const float* pts, int count, int win,
                  int max_level, int max_count, double epsilon, float* out_pts, uint8_t* status);
 
+/* ---- fallback estimator: phase correlation (vo_phase.c) ---- */
+int vo_optimal_dft_size(int n);
+void vo_phase_spectrum(const uint8_t* img, int h, int w, float* spectrum /*[M][N/2+1][2]*/);
+void vo_phase_correlate_clip(const uint8_t* gray, int n, int h, int w, double* shifts /*[n-1][3]*/,
+                             float* surface /*[M][N] of pair 0 or NULL*/);
+
 #ifdef __cplusplus
 }
 #endif

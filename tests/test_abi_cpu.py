@@ -219,3 +219,63 @@ def test_shake_generator_nodes(pkg):
     ref = sg.generate_shake_motion_meta(recipe=h, frame_count=12, width=64, height=48, fps=30.0, amount=1.0, speed=1.0, seed=0,
                                         node="shake_generator", style="handheld")
     assert out2["per_frame"] == ref["per_frame"]      # same recipe, same seed -> same motion
+
+
+def test_phase_oracle_against_float64_fft(oracle):
+    """oracle/vo_phase.c (own mixed-radix float DFT) vs the same published algorithm on numpy.fft in float64, and
+    exact recovery of circular shifts.  cv2.phaseCorrelate itself: parity unpinned (no OpenCV here)."""
+    rng = np.random.default_rng(3)
+
+    def np_phase(a, b):
+        h, w = a.shape
+        m, n = oracle.optimal_dft_size(h), oracle.optimal_dft_size(w)
+        pa, pb = np.zeros((m, n)), np.zeros((m, n))
+        pa[:h, :w], pb[:h, :w] = a, b
+        p = np.fft.fft2(pa) * np.conj(np.fft.fft2(pb))
+        c = np.real(np.fft.ifft2(p / (np.abs(p) + 1e-30))) * (m * n)
+        c = np.roll(c, (m // 2, n // 2), axis=(0, 1))
+        py, px = np.unravel_index(np.argmax(c), c.shape)
+        r0, r1, c0, c1 = max(py - 2, 0), min(py + 2, m - 1), max(px - 2, 0), min(px + 2, n - 1)
+        ys, xs = np.mgrid[r0:r1 + 1, c0:c1 + 1]
+        win = c[r0:r1 + 1, c0:c1 + 1]
+        return n / 2.0 - (xs * win).sum() / win.sum(), m / 2.0 - (ys * win).sum() / win.sum(), win.sum() / (m * n)
+
+    assert [oracle.optimal_dft_size(v) for v in (1, 7, 17, 135, 161, 540, 541, 960)] == [1, 8, 18, 135, 162, 540, 576, 960]
+    for h, w in [(135, 240), (100, 161), (270, 480)]:
+        base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        moved = np.roll(base, (4, -9), axis=(0, 1))
+        clip = np.stack([base, moved, base])
+        got = oracle.phase_correlate_clip(clip)
+        for p in range(2):
+            ref = np_phase(clip[p].astype(np.float64), clip[p + 1].astype(np.float64))
+            # the four purely real bins follow OpenCV's packed-format helpers (C = P/(P^2+eps) ~ 0 instead of +-1):
+            # at most 4 * 25 / (M N) in the window sum, far less in the centroid
+            assert abs(got[p, 0] - ref[0]) < 5e-3 and abs(got[p, 1] - ref[1]) < 5e-3 and abs(got[p, 2] - ref[2]) < 100.0 / (h * w) + 1e-4
+        if (oracle.optimal_dft_size(h), oracle.optimal_dft_size(w)) == (h, w):   # unpadded: the shift is circular
+            # phasecorr.cpp measures from (cols/2.0, rows/2.0) while fftShift centres on cols/2, rows/2 (integer):
+            # an odd side reports the shift + 0.5, as cv2.phaseCorrelate does
+            ox, oy = w / 2.0 - w // 2, h / 2.0 - h // 2
+            assert abs(got[0, 0] - (-9 + ox)) < 1e-3 and abs(got[0, 1] - (4 + oy)) < 1e-3
+            assert abs(got[1, 0] - (9 + ox)) < 1e-3 and abs(got[1, 1] - (-4 + oy)) < 1e-3
+
+
+def test_fallback_backend_selection(pkg, monkeypatch):
+    """flow.py:90-107 restated: DIS unless the fallback is requested; the phase table walks to all-translation."""
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import native
+
+    monkeypatch.delenv("VSTAB_FLOW_BACKEND", raising=False)
+    assert fp.resolve_flow_backend("flow") == "flow" and fp._backend_fields("flow") == {"flow_backend": "DIS", "flow_fallback_reason": None}
+    monkeypatch.setenv("VSTAB_FLOW_BACKEND", "phase_correlate")
+    assert fp.resolve_flow_backend("flow") == "flow_phase_correlate" and fp.resolve_flow_backend("classic") == "classic"
+    fields = fp._backend_fields("flow_phase_correlate")
+    assert fields["flow_backend"] == "phase_correlate" and "using phase correlation." in fields["flow_fallback_reason"]
+    table = np.zeros((4, 3), native.FIT_DTYPE)
+    table["matrix"][:] = np.eye(3, dtype=np.float32).reshape(9)
+    table["computed"][:, 0] = table["accepted"][:, 0] = 1
+    table["matrix"][:, 0, 2] = [1.5, -2.0, 0.25, 3.0]
+    table["confidence"][:, 0] = [0.9, 0.8, 0.7, 0.6]
+    for requested in ("translation", "similarity", "perspective"):
+        mats, modes, confs, resids, active = fp.select_transitions(table, requested)
+        assert modes == ["translation"] * 4 and active == "translation" and confs == [0.9, 0.8, 0.7, 0.6] and resids == [0.0] * 4
+        assert mats[:, 0, 2].tolist() == [1.5, -2.0, 0.25, 3.0]

@@ -1,0 +1,131 @@
+"""GPU parity: vstab_phase_correlate_batch (HIP) vs oracle/vo_phase.c -- the Flow node's fallback estimator
+(nodes/video_stabilizer_flow.py:110-130, cv2.phaseCorrelate).
+
+Tolerance: bit-exact against the oracle (same Stockham butterflies, same twiddle table, FMA contraction off, double
+products where OpenCV uses them).  Against a real OpenCV: parity unpinned (see oracle/vo_phase.c); the independent
+checks below are circular shifts, whose correlation surface is a single peak whatever the DFT rounding."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def textured_clip(n, h, w, seed):
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(seed)
+    big = gaussian_filter(rng.uniform(0, 255, (h + 48, w + 48)), 1.5)
+    big = (big - big.min()) / (big.max() - big.min()) * 255.0
+    frames, oy, ox = [], 24, 24
+    for i in range(n):
+        if i:
+            oy += int(rng.integers(-6, 7))
+            ox += int(rng.integers(-6, 7))
+            oy, ox = int(np.clip(oy, 0, 48)), int(np.clip(ox, 0, 48))
+        frames.append(big[oy:oy + h, ox:ox + w].astype(np.uint8))
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 135, 240), (3, 64, 96), (3, 45, 73), (2, 100, 161), (3, 540, 960), (5, 31, 17), (2, 1, 9)])
+def test_phase_matches_oracle(ctx, oracle, n, h, w):
+    import torch
+
+    gray = textured_clip(n, h, w, seed=h * 7 + w)
+    ref = oracle.phase_correlate_clip(gray)
+    table, shifts = ctx.phase_correlate_batch(torch.from_numpy(gray))
+    assert shifts.shape == ref.shape == (n - 1, 3)
+    assert np.array_equal(shifts, ref), f"max abs diff {np.abs(shifts - ref).max()}"
+    # record layout: only the translation row is usable, matrix = [1 0 tx; 0 1 ty; 0 0 1] in float32
+    assert (table["computed"][:, 0] == 1).all() and (table["accepted"][:, 0] == 1).all()
+    assert (table["computed"][:, 1:] == 0).all() and (table["accepted"][:, 1:] == 0).all()
+    mats = table["matrix"][:, 0].reshape(-1, 3, 3)
+    assert np.array_equal(mats[:, 0, 2], ref[:, 0].astype(np.float32)) and np.array_equal(mats[:, 1, 2], ref[:, 1].astype(np.float32))
+    assert np.array_equal(mats[:, :2, :2], np.broadcast_to(np.eye(2, dtype=np.float32), (n - 1, 2, 2)))
+    assert np.array_equal(table["confidence"][:, 0], ref[:, 2]) and (table["residual"] == 0).all()
+
+
+def test_phase_flat_frames_are_finite(ctx, oracle):
+    """Constant frames: zero spectrum except DC -> the helper's eps keeps everything finite (no NaN path)."""
+    import torch
+
+    gray = np.full((3, 40, 60), 128, np.uint8)
+    gray[2] = 0
+    ref = oracle.phase_correlate_clip(gray)
+    _, shifts = ctx.phase_correlate_batch(torch.from_numpy(gray))
+    assert np.array_equal(shifts, ref) and np.isfinite(shifts).all()
+
+
+def test_phase_recovers_circular_shift(ctx):
+    """Independent of the oracle: a circular shift of white noise correlates to a single peak."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (135, 240), dtype=np.uint8)   # 135 x 240 are optimal DFT sizes: no padding
+    moves = [(3, -2), (-7, 5), (0, 11)]
+    frames = [base]
+    for dx, dy in moves:
+        frames.append(np.roll(frames[-1], (dy, dx), axis=(0, 1)))
+    _, shifts = ctx.phase_correlate_batch(torch.from_numpy(np.stack(frames)))
+    for (dx, dy), row in zip(moves, shifts):
+        # odd height: OpenCV measures from rows/2.0 = 67.5 while the shifted origin sits at row 67 -> +0.5
+        assert abs(row[0] - dx) < 1e-3 and abs(row[1] - (dy + 0.5)) < 1e-3, (dx, dy, row)
+        assert 0.9 < row[2] <= 1.0 + 1e-4   # all energy in the peak window
+
+
+def test_phase_rejects_bad_arguments(ctx):
+    import torch
+
+    with pytest.raises(ValueError):
+        ctx.phase_correlate_batch(torch.zeros((1, 8, 8), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        ctx.phase_correlate_batch(torch.zeros((2, 8, 8), dtype=torch.float32))
+
+
+def test_flow_node_on_the_fallback_backend(pkg, ctx, oracle, monkeypatch):
+    """VSTAB_FLOW_BACKEND=phase_correlate: the Flow pipeline reports the fallback exactly as flow.py:98-107 / 325-330
+    would (backend name, reason, every transition a translation) and its frames equal a Motion Apply replay."""
+    import torch
+    from vstab_amd import apply_pipeline as ap
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    monkeypatch.setenv("VSTAB_FLOW_BACKEND", "phase_correlate")
+    n, h, w = 6, 96, 128
+    rng = np.random.default_rng(11)
+    base = rng.uniform(0, 1, (h, w, 3)).astype(np.float32)
+    frames = [base]
+    moves = [(2, 1), (-3, 2), (1, -2), (0, 3), (-2, -1)]
+    for dx, dy in moves:
+        frames.append(np.roll(frames[-1], (dy, dx), axis=(0, 1)))
+    frames = np.ascontiguousarray(np.stack(frames))
+    res = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", "similarity", False, 1.0, 0.5, 0.6,
+                               (127, 127, 127), 16.0)
+    meta = res.meta
+    assert meta["flow_backend"] == "phase_correlate"
+    assert meta["flow_fallback_reason"].startswith("DIS unavailable (") and meta["flow_fallback_reason"].endswith("using phase correlation.")
+    assert meta["transform_mode_requested"] == "similarity" and meta["transform_mode_applied"] == "translation"
+    assert meta["motion_meta"]["source"] == "estimated_flow"
+    trans = meta["estimated_motion"]["per_transition"]
+    assert len(trans) == n - 1 and all(t["mode"] == "translation" for t in trans)
+    mats = np.asarray([t["matrix"] for t in trans], np.float64).reshape(-1, 3, 3)
+    for (dx, dy), t, m in zip(moves, trans, mats):
+        assert abs(m[0, 2] - dx) < 1e-2 and abs(m[1, 2] - dy) < 1e-2 and np.array_equal(m[:2, :2], np.eye(2))
+        assert t["residual"] == 0.0 and t["confidence"] > 0.5
+    # the estimator leg against the oracle on the same gray images (no working-size rescale at this size)
+    gray = ctx.gray_downscale(torch.from_numpy(frames).to(ctx.device), None).cpu().numpy()
+    ref = oracle.phase_correlate_clip(gray)
+    assert np.array_equal(mats[:, :2, 2].astype(np.float32), ref[:, :2].astype(np.float32))
+    assert [t["confidence"] for t in trans] == ref[:, 2].tolist()
+    # KA7: replay through Motion Apply is bit-identical
+    replay = ap.apply_motion(hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop_and_pad")
+    assert np.array_equal(replay.frames, res.frames) and np.array_equal(replay.masks, res.masks)
+
+
+def test_unknown_backend_request_is_an_error(pkg, monkeypatch):
+    from vstab_amd import flow_pipeline as fp
+
+    monkeypatch.setenv("VSTAB_FLOW_BACKEND", "TVL1")
+    with pytest.raises(ValueError, match="VSTAB_FLOW_BACKEND"):
+        fp.resolve_flow_backend("flow")
+    assert fp.resolve_flow_backend("classic") == "classic"
