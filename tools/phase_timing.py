@@ -41,9 +41,11 @@ ctx.set_timing(True)
 t0 = time.perf_counter()
 for _ in range(5):
     res = step()
+    meta = res.meta
+    del res          # as bench.py: outputs of the previous pass are released before the next one allocates
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 stages = {k: ctx.kernel_ms_stats(k)[0] / max(ctx.kernel_ms_stats(k)[1], 1) for k in ("gray", "phase", "warp")}
-print(json.dumps({"backend": res.meta["flow_backend"], "ms_per_clip": round(dt * 1e3, 3), "frames_per_s": round(n / dt, 1),
+print(json.dumps({"backend": meta["flow_backend"], "ms_per_clip": round(dt * 1e3, 3), "frames_per_s": round(n / dt, 1),
                   "stage_ms": {k: round(v, 3) for k, v in stages.items()},
-                  "modes": sorted(set(t["mode"] for t in res.meta["estimated_motion"]["per_transition"]))}))
+                  "modes": sorted(set(t["mode"] for t in meta["estimated_motion"]["per_transition"]))}))
