@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir, estimator):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("estimator", ["flow", "classic"])
+@pytest.mark.parametrize("estimator", ["flow", "classic", "flow_phase_correlate"])
 def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path, estimator):
     import torch.multiprocessing as mp
 
