@@ -22,6 +22,7 @@
 #include "vstab_internal.h"
 #include <cmath>
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -38,6 +39,40 @@ struct FftPlan {
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
+// One Stockham stage of radix R over `len` points: a -> b.  Every butterfly is computed by one thread, operations in
+// the order of oracle/vo_phase.c (twiddle the inputs, then the R-point DFT as a running sum over q).
+template <int R>
+__device__ __forceinline__ void fft_stage(const float2* a, float2* b, int len, int ns, const float2* __restrict__ tw, bool inverse)
+{
+    const int m = len / R;
+    const int tstep = len / (ns * R);
+    for (int j = threadIdx.x; j < m; j += PC_T) {
+        const int k = j % ns;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v[q] = a[j + q * m];
+            if (q) {
+                float2 t = tw[q * k * tstep];
+                if (inverse) t.y = -t.y;
+                v[q] = cmul(v[q], t);
+            }
+        }
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            float2 acc = v[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                float2 t = tw[((p * q) % R) * m];
+                if (inverse) t.y = -t.y;
+                acc = cadd(acc, cmul(v[q], t));
+            }
+            b[j0 + p * ns] = acc;
+        }
+    }
+}
+
 // In-LDS Stockham transform of `plan.len` points held in `a` (scratch `b`); returns the array holding the result.
 // tw[t] = exp(-2 pi i t / len); `inverse` conjugates the twiddles (no scaling).
 __device__ float2* fft_lds(float2* a, float2* b, const FftPlan& plan, const float2* __restrict__ tw, bool inverse)
@@ -46,32 +81,10 @@ __device__ float2* fft_lds(float2* a, float2* b, const FftPlan& plan, const floa
     int ns = 1;
     for (int s = 0; s < plan.stages; ++s) {
         const int r = plan.radix[s];
-        const int m = len / r;
-        const int tstep = len / (ns * r);
-        const int rstep = len / r;
         __syncthreads();
-        for (int j = threadIdx.x; j < m; j += PC_T) {
-            const int k = j % ns;
-            float2 v[5];
-            for (int q = 0; q < r; ++q) {
-                v[q] = a[j + q * m];
-                if (q) {
-                    float2 t = tw[q * k * tstep];
-                    if (inverse) t.y = -t.y;
-                    v[q] = cmul(v[q], t);
-                }
-            }
-            const int j0 = (j - k) * r + k;
-            for (int p = 0; p < r; ++p) {
-                float2 acc = v[0];
-                for (int q = 1; q < r; ++q) {
-                    float2 t = tw[((p * q) % r) * rstep];
-                    if (inverse) t.y = -t.y;
-                    acc = cadd(acc, cmul(v[q], t));
-                }
-                b[j0 + p * ns] = acc;
-            }
-        }
+        if (r == 2) fft_stage<2>(a, b, len, ns, tw, inverse);
+        else if (r == 3) fft_stage<3>(a, b, len, ns, tw, inverse);
+        else fft_stage<5>(a, b, len, ns, tw, inverse);
         ns *= r;
         float2* t = a; a = b; b = t;
     }
@@ -305,6 +318,7 @@ extern "C" int vstab_phase_correlate_batch(vstab_ctx* ctx, const uint8_t* gray, 
     // pairs per pass: spectra of chunk+1 frames, cross-power planes, real planes and row maxima under ~1 GiB
     const size_t spec_b = (size_t)M * nh * sizeof(float2), real_b = (size_t)M * N * sizeof(float);
     int chunk = (int)((size_t(1) << 30) / (2 * spec_b + real_b + (size_t)M * sizeof(RowBest)));
+    if (const char* e = getenv("VSTAB_PHASE_CHUNK")) { const int v = atoi(e); if (v > 0 && v < chunk) chunk = v; }   // tests: force several passes
     chunk = chunk < 1 ? 1 : (chunk > pairs ? pairs : chunk);
     const size_t f_b = align256(spec_b * (chunk + 1)), g_b = align256(spec_b * chunk), r_b = align256(real_b * chunk);
     const size_t best_b = align256(sizeof(RowBest) * (size_t)M * chunk), out_b = align256(sizeof(double) * 3 * (size_t)pairs);

@@ -45,6 +45,17 @@ def test_phase_matches_oracle(ctx, oracle, n, h, w):
     assert np.array_equal(table["confidence"][:, 0], ref[:, 2]) and (table["residual"] == 0).all()
 
 
+def test_phase_multi_pass_clip(ctx, oracle, monkeypatch):
+    """Long clips are processed in passes that share one frame; VSTAB_PHASE_CHUNK forces 2-pair passes here."""
+    import torch
+
+    monkeypatch.setenv("VSTAB_PHASE_CHUNK", "2")
+    gray = textured_clip(8, 54, 96, seed=77)
+    ref = oracle.phase_correlate_clip(gray)
+    _, shifts = ctx.phase_correlate_batch(torch.from_numpy(gray))
+    assert np.array_equal(shifts, ref)
+
+
 def test_phase_flat_frames_are_finite(ctx, oracle):
     """Constant frames: zero spectrum except DC -> the helper's eps keeps everything finite (no NaN path)."""
     import torch
