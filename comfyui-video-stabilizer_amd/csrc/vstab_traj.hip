@@ -44,6 +44,50 @@ __global__ __launch_bounds__(256) void trajectory_kernel(const double* __restric
     }
 }
 
+// Same arithmetic with the path held in LDS (n*p doubles): the deltas arrive with one coalesced pass, the sequential
+// prefix sums (one lane per parameter, fixed order) run on LDS latency instead of a global load/store per frame, and
+// the window sums read LDS.  Used whenever the path fits (multi-GPU runs smooth the whole clip on every rank).
+constexpr int TRAJ_T = 1024;
+constexpr size_t TRAJ_LDS_MAX = 144 * 1024;
+
+__global__ __launch_bounds__(TRAJ_T) void trajectory_lds_kernel(const double* __restrict__ deltas, double* __restrict__ path,
+                                                                double* __restrict__ target, int n, int p, int window, int do_smooth,
+                                                                double strength, int camera_lock)
+{
+    extern __shared__ double s_path[];
+    const int total = n * p;
+    for (int t = threadIdx.x; t < total; t += TRAJ_T) s_path[t] = t < p ? 0.0 : deltas[t - p];
+    __syncthreads();
+    if ((int)threadIdx.x < p) {
+        const int c = threadIdx.x;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int i = 1; i < n; i++) {
+            acc = acc + s_path[i * p + c];
+            s_path[i * p + c] = acc;
+        }
+    }
+    __syncthreads();
+    const int pad = window / 2;
+    const double kv = 1.0 / (double)window;
+    for (int t = threadIdx.x; t < total; t += TRAJ_T) {
+        const int i = t / p, c = t - i * p;
+        const double cur = s_path[t];
+        double sm = cur;
+        if (do_smooth) {
+            double acc = 0.0;
+            for (int k = 0; k < window; k++) {
+                int s = i + k - pad;
+                s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
+                acc += s_path[s * p + c] * kv;
+            }
+            sm = acc;
+        }
+        path[t] = cur;
+        target[t] = camera_lock ? 0.0 : cur + strength * (sm - cur);
+    }
+}
+
 }  // namespace
 
 extern "C" int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double smooth, double fps,
@@ -71,8 +115,16 @@ extern "C" int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int
     if (ctx->h_fit.reserve(2 * out_bytes)) return 1;
     double* d_path = static_cast<double*>(ctx->d_fit.ptr);
     double* d_target = d_path + (size_t)n * p;
-    hipLaunchKernelGGL(trajectory_kernel, dim3(1), dim3(256), 0, ctx->stream, static_cast<const double*>(d_in), d_path, d_target, n, p,
-                       window, do_smooth, strength, camera_lock);
+    const size_t lds = out_bytes;
+    if (lds <= TRAJ_LDS_MAX) {
+        if (lds > 64 * 1024)
+            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trajectory_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(trajectory_lds_kernel, dim3(1), dim3(TRAJ_T), lds, ctx->stream, static_cast<const double*>(d_in), d_path, d_target, n,
+                           p, window, do_smooth, strength, camera_lock);
+    } else {
+        hipLaunchKernelGGL(trajectory_kernel, dim3(1), dim3(256), 0, ctx->stream, static_cast<const double*>(d_in), d_path, d_target, n, p,
+                           window, do_smooth, strength, camera_lock);
+    }
     VSTAB_HIP(hipGetLastError());
     VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_path, 2 * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));

@@ -82,11 +82,12 @@ def test_fit_too_few_valid_points(ctx):
 
 
 @pytest.mark.parametrize("smooth,fps", [(0.0, 16.0), (0.5, 16.0), (1.0, 24.0), (0.5, 60.0), (0.3, 30.0)])
-@pytest.mark.parametrize("p", [2, 4, 8])
-def test_trajectory_matches_numpy(ctx, smooth, fps, p):
-    """fp64 restatement of flow.py:356-371 + utils.py:361-383 written with NumPy in the test."""
+@pytest.mark.parametrize("p,n", [(2, 97), (4, 97), (8, 97), (4, 2048), (8, 2048), (8, 5000)])
+def test_trajectory_matches_numpy(ctx, smooth, fps, p, n):
+    """fp64 restatement of flow.py:356-371 + utils.py:361-383 written with NumPy in the test.  The sizes cover the
+    kernel with the path in LDS (below and above the 64 KB default limit) and the global-memory kernel for paths that
+    do not fit (8 x 5000 doubles)."""
     rng = np.random.default_rng(int(fps) + p)
-    n = 97
     deltas = rng.normal(0, 1.5, (n - 1, p))
     path, target = ctx.trajectory(deltas, smooth, fps, 0.7, False)
     ref_path = np.zeros((n, p))
