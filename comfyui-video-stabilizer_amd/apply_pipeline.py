@@ -67,19 +67,6 @@ def _resolve_motion_for_context(meta: Dict[str, Any], context: hm.VideoContext) 
     return resolve_motion_meta(meta)
 
 
-def _blurred_matrix_samples(matrices: List[np.ndarray], idx: int, motion_blur: float, sample_count: int) -> List[np.ndarray]:
-    """Host restatement of motion_apply.py:125-134 (the library does the same in C for all frames);
-    kept for tests and for callers that want to inspect the shutter samples."""
-    if len(matrices) <= 1:
-        return [matrices[idx]]
-    base = np.asarray(matrices[idx], dtype=np.float64)
-    if idx < len(matrices) - 1:
-        delta = np.asarray(matrices[idx + 1], dtype=np.float64) - base
-    else:
-        delta = base - np.asarray(matrices[idx - 1], dtype=np.float64)
-    return [base + delta * t for t in np.linspace(0.0, float(motion_blur), int(sample_count), dtype=np.float64)]
-
-
 def _tick(cb: Optional[ProgressCallback], times: int) -> None:
     if cb is not None:
         for _ in range(int(times)):
@@ -87,32 +74,40 @@ def _tick(cb: Optional[ProgressCallback], times: int) -> None:
 
 
 def _warp(ctx, device_frames, matrices, output_size, interpolation, padding_rgb, motion_blur, samples, *,
-          masks_zero: bool, progress_callback):
-    """motion_apply.py:75-202 for the whole clip: returns device tensors (frames, masks[N,h,w])."""
+          masks_zero: bool, progress_callback, first: int = 0):
+    """motion_apply.py:75-202 for frames [first, first+n) of the clip whose motion is `matrices` (all frames of the
+    clip; a single-process call has first == 0 and n == len(matrices)): returns device tensors (frames, masks[n,h,w])."""
     n = device_frames.shape[0]
+    total = len(matrices)
     border = hm.border_value(padding_rgb)
+    if n == 0:   # a rank that owns no frames of the clip (multi-GPU, clip shorter than the world): shapes only
+        empty = ctx.torch.empty((0, int(output_size[1]), int(output_size[0]), 3), dtype=ctx.torch.float32, device=ctx.device)
+        return empty, empty[..., 0]
     if motion_blur <= 0.0 or samples <= 1:
-        m32 = np.stack([np.asarray(m, dtype=np.float32) for m in matrices])
+        m32 = np.stack([np.asarray(m, dtype=np.float32) for m in matrices[first:first + n]])
         dst, mask, _ = ctx.warp_batch(device_frames, m32, output_size, interp=interpolation, border=border,
                                       want_mask=not masks_zero)
         _tick(progress_callback, n)
     else:
         s = int(np.clip(samples, 3, 33))
         m64 = np.stack([np.asarray(m, dtype=np.float64) for m in matrices])
+        # the sample matrices of a frame need its neighbour's matrix (motion_apply.py:125-134), never its pixels:
+        # the whole table goes down, the library picks rows [first, first+n) (vstab_warp_blur_clip_batch)
         dst, mask = ctx.warp_blur_batch(device_frames, m64, output_size, float(motion_blur), s, interp=interpolation,
-                                        border=border, want_mask=not masks_zero)
-        _tick(progress_callback, n * (s if n > 1 else 1))
+                                        border=border, want_mask=not masks_zero, clip_first=first)
+        _tick(progress_callback, n * (s if total > 1 else 1))
     if mask is None:
         mask = ctx.torch.zeros((n, int(output_size[1]), int(output_size[0])), dtype=ctx.torch.float32, device=ctx.device)
     return dst, mask
 
 
-def _common_valid_mask(ctx, device_frames, input_size, output_size, matrices, progress_callback) -> np.ndarray:
-    """AND over frames of the nearest-neighbour coverage (motion_apply.py:205-227)."""
+def _common_valid_mask(ctx, input_size, output_size, matrices, first, count, progress_callback) -> np.ndarray:
+    """AND over ALL frames of the clip of the nearest-neighbour coverage (motion_apply.py:205-227): coverage only, no
+    pixels are read (vstab_common_coverage), so a shard evaluates the whole clip's matrices itself; it ticks for its
+    own `count` frames."""
     m32 = np.stack([np.asarray(m, dtype=np.float32) for m in matrices])
-    _, mask, _ = ctx.warp_batch(device_frames, m32, output_size, interp="bilinear", border=(0.0, 0.0, 0.0), want_mask=True)
-    common = (mask.amax(dim=0) < 0.5).cpu().numpy()
-    _tick(progress_callback, len(matrices))
+    common = ctx.common_coverage(m32, input_size, output_size)
+    _tick(progress_callback, count)
     return common
 
 
@@ -163,22 +158,13 @@ def _expand_matrices(matrices: List[np.ndarray], input_size: Tuple[int, int]):
     return [shift @ m for m in matrices], output_size
 
 
-def apply_motion(
-    context: hm.VideoContext,
-    meta: Dict[str, Any],
-    padding_rgb: Tuple[int, int, int],
-    *,
-    framing_mode: str = "crop_and_pad",
-    interpolation: str = "bilinear",
-    motion_blur: float = 0.0,
-    motion_blur_samples: int = 9,
-    progress_callback: Optional[ProgressCallback] = None,
-    ctx: Optional[native.Context] = None,
-    keep_on_device: bool = False,
-) -> MotionApplyResult:
-    """Signature of the reference's apply_motion (motion_apply.py:297-307) plus GPU-context extras."""
-    motion = _resolve_motion_for_context(meta, context)
-    _validate_context(context, motion)
+def apply_motion_on_device(ctx, device_frames, first: int, motion: MotionMeta, meta: Dict[str, Any], padding_rgb, *,
+                           framing_mode: str, interpolation: str, motion_blur: float, motion_blur_samples: int,
+                           progress_callback: Optional[ProgressCallback] = None):
+    """motion_apply.py:311-428 for frames [first, first + n) of the clip described by `motion` (already resolved and
+    validated).  Everything that spans the clip -- the common coverage of `crop`, the bounding box of `expand`, the
+    neighbour matrix of a blurred frame -- is a function of the replicated matrices alone, so a shard needs no
+    exchange with other ranks.  Returns device tensors (frames [n,h,w,3], masks [n,h,w]) and the meta."""
     matrices = [t.matrix for t in motion.per_frame]
     output_size = motion.output_size
     interpolation = _check_interpolation(interpolation)
@@ -190,14 +176,12 @@ def apply_motion(
     if requested not in ("crop_and_pad", "crop", "expand"):
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop_and_pad', 'crop', or 'expand'.")
 
-    ctx = ctx or native.default_context()
-    device_frames = context.device_batch(ctx)
-    kw = dict(progress_callback=progress_callback)
+    kw = dict(progress_callback=progress_callback, first=first)
     if requested == "crop_and_pad":
         frames, masks = _warp(ctx, device_frames, matrices, output_size, interpolation, padding_rgb, motion_blur,
                               motion_blur_samples, masks_zero=False, **kw)
     elif requested == "crop":
-        common = _common_valid_mask(ctx, device_frames, motion.input_size, output_size, matrices, progress_callback)
+        common = _common_valid_mask(ctx, motion.input_size, output_size, matrices, first, device_frames.shape[0], progress_callback)
         crop_matrix = _center_crop_matrix_from_common(common, output_size)
         if crop_matrix is None:
             frames, masks = _warp(ctx, device_frames, matrices, output_size, interpolation, padding_rgb, motion_blur,
@@ -222,6 +206,33 @@ def apply_motion(
         "motion_blur_samples": motion_blur_samples,
         "source": motion.source,
     }
+    return frames, masks, result_meta
+
+
+def apply_motion(
+    context: hm.VideoContext,
+    meta: Dict[str, Any],
+    padding_rgb: Tuple[int, int, int],
+    *,
+    framing_mode: str = "crop_and_pad",
+    interpolation: str = "bilinear",
+    motion_blur: float = 0.0,
+    motion_blur_samples: int = 9,
+    progress_callback: Optional[ProgressCallback] = None,
+    ctx: Optional[native.Context] = None,
+    keep_on_device: bool = False,
+) -> MotionApplyResult:
+    """Signature of the reference's apply_motion (motion_apply.py:297-307) plus GPU-context extras."""
+    motion = _resolve_motion_for_context(meta, context)
+    _validate_context(context, motion)
+    _check_interpolation(interpolation)
+    if ("crop_and_pad" if framing_mode == "pad" else framing_mode) not in ("crop_and_pad", "crop", "expand"):
+        raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop_and_pad', 'crop', or 'expand'.")
+    ctx = ctx or native.default_context()
+    device_frames = context.device_batch(ctx)
+    frames, masks, result_meta = apply_motion_on_device(
+        ctx, device_frames, 0, motion, meta, padding_rgb, framing_mode=framing_mode, interpolation=interpolation,
+        motion_blur=motion_blur, motion_blur_samples=motion_blur_samples, progress_callback=progress_callback)
     if keep_on_device:
         return MotionApplyResult(frames, masks.unsqueeze(-1), result_meta)
     return MotionApplyResult(frames.cpu().numpy(), masks.cpu().numpy()[..., np.newaxis], result_meta)

@@ -102,6 +102,21 @@ int vstab_timer_fold(EventPair* ev)
     return 0;
 }
 
+int vstab_check_device_status(vstab_ctx* ctx, const char* who)
+{
+    if (!ctx || !ctx->h_status) return 0;
+    const int word = *ctx->h_status;
+    if (word == 0) return 0;
+    *ctx->h_status = 0;
+    if (word & VSTAB_STATUS_PIS_TIMEOUT)
+        vstab_set_error("%s: the DIS patch inverse search reported an expired dependency wait (status 0x%x): a wave did not see "
+                        "its neighbour row's progress counter advance within the spin bound, the flow of this call is invalid",
+                        who, word);
+    else
+        vstab_set_error("%s: device-side failure report, status 0x%x", who, word);
+    return 3;
+}
+
 extern "C" {
 
 int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
@@ -123,6 +138,15 @@ int vstab_create(vstab_ctx** out, int device)
     ctx->h_fit.pinned_host = true;
     VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_params_free, hipEventDisableTiming));
     VSTAB_HIP(hipEventRecord(ctx->ev_params_free, nullptr));
+    {
+        void* h = nullptr;
+        VSTAB_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h, 0, 64);
+        void* d = nullptr;
+        VSTAB_HIP(hipHostGetDevicePointer(&d, h, 0));
+        ctx->h_status = static_cast<volatile int*>(h);
+        ctx->d_status = static_cast<int*>(d);
+    }
     *out = ctx;
     return 0;
 }
@@ -140,6 +164,7 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->d_gray_tmp.release();
     for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
+    if (ctx->h_status) (void)hipHostFree(const_cast<int*>(ctx->h_status));
     delete ctx;
     return 0;
 }
@@ -155,8 +180,9 @@ int vstab_synchronize(vstab_ctx* ctx)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_synchronize: ctx is NULL");
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return vstab_check_device_status(ctx, "vstab_synchronize");
 }
+
 
 int vstab_set_timing(vstab_ctx* ctx, int enabled)
 {

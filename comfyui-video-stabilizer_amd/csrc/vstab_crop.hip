@@ -132,6 +132,32 @@ __global__ __launch_bounds__(256) void erode3_kernel(const uint8_t* __restrict__
     }
 }
 
+// AND over all frames of the nearest coverage, one thread per output pixel (no per-frame planes in memory)
+__global__ __launch_bounds__(256) void common_coverage_kernel(const CovXform* __restrict__ xf, uint8_t* __restrict__ common, int n, int sh,
+                                                              int sw, int dh, int dw, int bw0)
+{
+    const int npx = dh * dw;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += gridDim.x * blockDim.x) {
+        const int y = p / dw, x = p - y * dw;
+        const int xb = (bw0 >= dw) ? 0 : (x / bw0) * bw0;
+        const double dxb = (double)xb, dy = (double)y, dx1 = (double)(x - xb);
+        int all = 1;
+        for (int f = 0; f < n && all; f++) {
+            const CovXform& X = xf[f];
+            const double X0 = X.m[0] * dxb + X.m[1] * dy + X.m[2];
+            const double Y0 = X.m[3] * dxb + X.m[4] * dy + X.m[5];
+            const double W0 = X.m[6] * dxb + X.m[7] * dy + X.m[8];
+            double Wn;
+            if (X.affine) Wn = X.wn;
+            else { const double W = W0 + X.m[6] * dx1; Wn = (W != 0.0) ? 1.0 / W : 0.0; }
+            const int nx = sat_short(clamp_round_i32((X0 + X.m[0] * dx1) * Wn));
+            const int ny = sat_short(clamp_round_i32((Y0 + X.m[3] * dx1) * Wn));
+            all &= ((unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh) ? 1 : 0;
+        }
+        common[p] = (uint8_t)all;
+    }
+}
+
 unsigned grid_for(long long items)
 {
     long long b = (items + 255) / 256;
@@ -140,7 +166,49 @@ unsigned grid_for(long long items)
     return (unsigned)b;
 }
 
+int stage_cov_xforms(vstab_ctx* ctx, const float* matrices, int n, void** d_xf)
+{
+    std::vector<CovXform> xf((size_t)n);
+    for (int i = 0; i < n; i++) {
+        double M[9];
+        for (int j = 0; j < 9; j++) M[j] = (double)matrices[(size_t)i * 9 + j];
+        vstab_invert3x3(M, xf[i].m);
+        xf[i].affine = (xf[i].m[6] == 0.0 && xf[i].m[7] == 0.0) ? 1 : 0;
+        xf[i].wn = (xf[i].m[8] != 0.0) ? 1.0 / xf[i].m[8] : 0.0;
+        xf[i].pad_ = 0;
+    }
+    return vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(CovXform), d_xf);
+}
+
 }  // namespace
+
+extern "C" int vstab_common_coverage(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w, int out_h, int out_w,
+                                     uint8_t* common)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_common_coverage: ctx is NULL");
+    VSTAB_REQUIRE(matrices && common, "vstab_common_coverage: NULL pointer argument");
+    VSTAB_REQUIRE(n > 0 && src_h > 0 && src_w > 0 && out_h > 0 && out_w > 0, "vstab_common_coverage: non-positive size");
+    VSTAB_REQUIRE(src_h <= 32767 && src_w <= 32767, "vstab_common_coverage: source larger than 32767 px");
+    VSTAB_REQUIRE((long long)out_h * out_w < 0x7fffffffLL, "vstab_common_coverage: output too large");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void* d_xf = nullptr;
+    if (stage_cov_xforms(ctx, matrices, n, &d_xf)) return 1;
+    const size_t npx = (size_t)out_h * out_w;
+    if (ctx->d_gray_tmp.reserve(npx + 256)) return 1;
+    if (ctx->h_fit.reserve(npx)) return 1;
+    uint8_t* d_common = static_cast<uint8_t*>(ctx->d_gray_tmp.ptr);
+    const int BLOCK_SZ = 32;
+    int bh0 = BLOCK_SZ / 2 < out_h ? BLOCK_SZ / 2 : out_h;
+    int bw0 = BLOCK_SZ * BLOCK_SZ / bh0 < out_w ? BLOCK_SZ * BLOCK_SZ / bh0 : out_w;
+    hipLaunchKernelGGL(common_coverage_kernel, dim3(grid_for((long long)npx)), dim3(256), 0, st, static_cast<const CovXform*>(d_xf), d_common,
+                       n, src_h, src_w, out_h, out_w, bw0);
+    VSTAB_HIP(hipGetLastError());
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_common, npx, hipMemcpyDeviceToHost, st));
+    VSTAB_HIP(hipStreamSynchronize(st));
+    memcpy(common, ctx->h_fit.ptr, npx);
+    return 0;
+}
 
 extern "C" int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w, int out_h, int out_w,
                                    int32_t* bbox, uint8_t* common)
@@ -151,17 +219,8 @@ extern "C" int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n,
     VSTAB_REQUIRE(src_h <= 32767 && src_w <= 32767, "vstab_crop_analysis: source larger than 32767 px");
     VSTAB_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    std::vector<CovXform> xf((size_t)n);
-    for (int i = 0; i < n; i++) {
-        double M[9];
-        for (int j = 0; j < 9; j++) M[j] = (double)matrices[(size_t)i * 9 + j];
-        vstab_invert3x3(M, xf[i].m);
-        xf[i].affine = (xf[i].m[6] == 0.0 && xf[i].m[7] == 0.0) ? 1 : 0;
-        xf[i].wn = (xf[i].m[8] != 0.0) ? 1.0 / xf[i].m[8] : 0.0;
-        xf[i].pad_ = 0;
-    }
     void* d_xf = nullptr;
-    if (vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(CovXform), &d_xf)) return 1;
+    if (stage_cov_xforms(ctx, matrices, n, &d_xf)) return 1;
     const size_t npx = (size_t)out_h * out_w;
     const size_t need = 2 * (size_t)n * npx + 2 * npx + sizeof(int) * 4 * (size_t)n + 1024;
     if (ctx->d_gray_tmp.reserve(need)) return 1;

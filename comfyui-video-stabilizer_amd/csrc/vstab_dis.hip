@@ -285,6 +285,8 @@ struct PisArgs {
     float* Sx;             // [P][hs][ws]
     float* Sy;
     int n, w, h, ws, hs, stripe_sz;
+    int spin_limit;        // bound of the LDS progress-counter waits (VSTAB_DEBUG_PIS_SPIN_LIMIT overrides it in tests)
+    int* status;           // host-mapped status word of the context (vstab_internal.h): a timed-out wait is reported there
 };
 
 // Two 1024-thread workgroups per frame pair; each owns 4 of OpenCV's 8 fixed stripes and runs 4 waves per
@@ -295,14 +297,19 @@ struct PisArgs {
 // candidate -> bilinear window -> sums -> update never leaves the CU.
 constexpr int PIS_STRIPES_PER_BLOCK = 4;
 
-__device__ __forceinline__ void wait_progress(volatile int* counter, int need)
+__device__ __forceinline__ void wait_progress(volatile int* counter, int need, int limit, int* status)
 {
-    // bounded spin (every wave of the workgroup is resident, so the producer always makes progress; the bound
-    // only turns a logic error into wrong output instead of a hung GPU)
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
+    // bounded spin (every wave of the workgroup is resident, so the producer always makes progress; the bound turns a
+    // logic error into a reported failure instead of a hung GPU: the wave records VSTAB_STATUS_PIS_TIMEOUT in the
+    // context's host-visible status word and carries on, and the next host synchronisation point of the library
+    // (vstab_sample_fit_batch, vstab_synchronize) returns non-zero with vstab_last_error() set)
+    for (int spin = 0; spin < limit; spin++) {
+        if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
         __builtin_amdgcn_s_sleep(1);
     }
+    if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
+    if (status != nullptr && (threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_or(status, VSTAB_STATUS_PIS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Residency: the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) waves per SIMD, i.e. 8 only up to 80 SGPRs
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256 * PIS_ROW_WAVES) __attribute__((amdgpu_num_sgpr
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                 }
                 if (has_vert) {
-                    wait_progress(done + (is - dir), visited + 1);   // the row above/below has finished this column
+                    wait_progress(done + (is - dir), visited + 1, a.spin_limit, a.status);   // the row above/below has finished this column
                     const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
                     SSD_AT(cur_SSD, nx, ny);
                     if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
@@ -537,13 +544,13 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
             if (iter == 1) {
                 // the backward pass starts from this row's forward-pass result; the pairing (hence the wavefront that
                 // produced it) may differ between the passes, so wait for the forward pass of both rows
-                wait_progress(done0 + row_a, ws);
-                if (b_valid) wait_progress(done0 + (row_a + dir), ws);
+                wait_progress(done0 + row_a, ws, a.spin_limit, a.status);
+                if (b_valid) wait_progress(done0 + (row_a + dir), ws, a.spin_limit, a.status);
             }
             for (int s = 0; s <= ws; s++) {
                 const int visited = s - H;                             // patches this half finished before this step
                 const bool act = row_ok && visited >= 0 && visited < ws;
-                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1);   // leading row's vertical neighbour (other wave)
+                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, a.spin_limit, a.status);   // leading row's vertical neighbour (other wave)
                 if (act) {
                     const int js = start_js + dir * visited;
                     const int j = js * PSTR;
@@ -1190,6 +1197,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
         pa.stripe_sz = (int)std::ceil(g.hs / 8.0);
+        pa.spin_limit = 1 << 22;
+        if (const char* e = getenv("VSTAB_DEBUG_PIS_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // tests: 0 forces the timeout report
+        pa.status = ctx->d_status;
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
         // rows of a stripe are pipelined over 4 waves only where a stripe has enough rows to pay for it

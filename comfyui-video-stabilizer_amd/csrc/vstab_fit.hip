@@ -421,7 +421,9 @@ static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pai
     VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(results, ctx->h_fit.ptr, rec_bytes);
-    return 0;
+    // the flow these fits were computed from was produced asynchronously by vstab_dis_flow_batch on the same stream:
+    // this is the first host synchronisation after it, so a device-side failure report of DIS surfaces here
+    return vstab_check_device_status(ctx, "vstab_sample_fit_batch");
 }
 
 extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw, int step,

@@ -58,7 +58,17 @@ struct vstab_ctx {
     hipEvent_t ev_params_free = nullptr;  // recorded after the H2D copy of h_params
     // DIS / fit workspaces (grow-only)
     ScratchBuf d_dis, d_fit, h_fit, d_gray_tmp;
+    // Device-side failure reports: one host-resident word (coherent, device-mapped).  A kernel ORs a VSTAB_STATUS_*
+    // bit into it through d_status; the host reads h_status after any stream synchronisation at no cost.
+    volatile int* h_status = nullptr;
+    int* d_status = nullptr;
 };
+
+enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired
+
+// Call after a host synchronisation of ctx->stream: turns a device-side failure report into a non-zero return
+// (rc 3) with vstab_last_error() set, and clears the word.
+int vstab_check_device_status(vstab_ctx* ctx, const char* who);
 
 // Upload `bytes` of host data through the pinned staging buffer; returns device pointer.
 int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** dev_out);

@@ -464,30 +464,49 @@ extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src
     return launch_warp<false>(a, interp, subpix, mask != nullptr, ctx->stream);
 }
 
-extern "C" int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
-                                     const double* matrices, const double* ts, int samples, int out_h, int out_w,
-                                     int interp, const float* border_rgb, int subpix, float* dst, float* mask)
+// motion_apply.py:125-134 (_blurred_matrix_samples) + the f32 cast of motion_apply.py:172, for frames
+// [first, first+count) of a clip of `total` matrices.  Host arithmetic only.
+extern "C" int vstab_blur_sample_matrices(const double* matrices, int total, int first, int count, const double* ts,
+                                          int samples, float* out)
 {
-    if (int rc = check_common("vstab_warp_blur_batch", ctx, src, n, src_h, src_w, matrices, out_h, out_w, interp, border_rgb, subpix, dst)) return rc;
-    VSTAB_REQUIRE(ts != nullptr, "vstab_warp_blur_batch: ts is NULL");
-    VSTAB_REQUIRE(samples >= 1 && samples <= MAX_BLUR_SAMPLES, "vstab_warp_blur_batch: samples=%d outside [1,%d]", samples, MAX_BLUR_SAMPLES);
-    VSTAB_HIP(hipSetDevice(ctx->device));
-    // motion_apply.py:125-134: a single-frame clip yields one sample matrix (still divided by `samples`)
-    const int per_frame = (n <= 1) ? 1 : samples;
-    std::vector<WarpXform> xf((size_t)n * per_frame);
-    for (int i = 0; i < n; i++) {
+    VSTAB_REQUIRE(matrices && ts && out, "vstab_blur_sample_matrices: NULL pointer argument");
+    VSTAB_REQUIRE(total >= 1 && first >= 0 && count >= 1 && first + count <= total,
+                  "vstab_blur_sample_matrices: frames [%d, %d) outside a clip of %d matrices", first, first + count, total);
+    VSTAB_REQUIRE(samples >= 1 && samples <= MAX_BLUR_SAMPLES, "vstab_blur_sample_matrices: samples=%d outside [1,%d]", samples, MAX_BLUR_SAMPLES);
+    // a single-frame clip yields one sample matrix per frame (the caller still divides by `samples`)
+    const int per_frame = (total <= 1) ? 1 : samples;
+    for (int c = 0; c < count; c++) {
+        const int i = first + c;
         const double* base = matrices + (size_t)i * 9;
         double delta[9];
-        if (n > 1) {
-            if (i < n - 1) for (int j = 0; j < 9; j++) delta[j] = matrices[(size_t)(i + 1) * 9 + j] - base[j];
+        if (total > 1) {
+            if (i < total - 1) for (int j = 0; j < 9; j++) delta[j] = matrices[(size_t)(i + 1) * 9 + j] - base[j];
             else for (int j = 0; j < 9; j++) delta[j] = base[j] - matrices[(size_t)(i - 1) * 9 + j];
         }
         for (int k = 0; k < per_frame; k++) {
-            float m32[9];
-            for (int j = 0; j < 9; j++) m32[j] = (n > 1) ? (float)(base[j] + delta[j] * ts[k]) : (float)base[j];
-            fill_xform(m32, &xf[(size_t)i * per_frame + k]);
+            float* m32 = out + ((size_t)c * per_frame + k) * 9;
+            for (int j = 0; j < 9; j++) m32[j] = (total > 1) ? (float)(base[j] + delta[j] * ts[k]) : (float)base[j];
         }
     }
+    return 0;
+}
+
+extern "C" int vstab_warp_blur_clip_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                                          const double* clip_matrices, int clip_total, int clip_first, const double* ts,
+                                          int samples, int out_h, int out_w, int interp, const float* border_rgb, int subpix,
+                                          float* dst, float* mask)
+{
+    if (int rc = check_common("vstab_warp_blur_clip_batch", ctx, src, n, src_h, src_w, clip_matrices, out_h, out_w, interp, border_rgb, subpix, dst)) return rc;
+    VSTAB_REQUIRE(ts != nullptr, "vstab_warp_blur_clip_batch: ts is NULL");
+    VSTAB_REQUIRE(samples >= 1 && samples <= MAX_BLUR_SAMPLES, "vstab_warp_blur_clip_batch: samples=%d outside [1,%d]", samples, MAX_BLUR_SAMPLES);
+    VSTAB_REQUIRE(clip_first >= 0 && clip_first + n <= clip_total,
+                  "vstab_warp_blur_clip_batch: frames [%d, %d) outside a clip of %d matrices", clip_first, clip_first + n, clip_total);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const int per_frame = (clip_total <= 1) ? 1 : samples;
+    std::vector<float> m32((size_t)n * per_frame * 9);
+    if (int rc = vstab_blur_sample_matrices(clip_matrices, clip_total, clip_first, n, ts, samples, m32.data())) return rc;
+    std::vector<WarpXform> xf((size_t)n * per_frame);
+    for (size_t i = 0; i < xf.size(); i++) fill_xform(m32.data() + i * 9, &xf[i]);
     void* d_xf = nullptr;
     if (vstab_stage_params(ctx, xf.data(), xf.size() * sizeof(WarpXform), &d_xf)) return 1;
 
@@ -498,4 +517,12 @@ extern "C" int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, in
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     KernelTimer timer(ctx, "warp_blur");
     return launch_warp<true>(a, interp, subpix, mask != nullptr, ctx->stream);
+}
+
+extern "C" int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                                     const double* matrices, const double* ts, int samples, int out_h, int out_w,
+                                     int interp, const float* border_rgb, int subpix, float* dst, float* mask)
+{
+    return vstab_warp_blur_clip_batch(ctx, src, n, src_h, src_w, matrices, n, 0, ts, samples, out_h, out_w, interp, border_rgb,
+                                      subpix, dst, mask);
 }

@@ -14,6 +14,11 @@ scale-out of its path, following SURVEY 8(e):
   * the warp is embarrassingly parallel over the rank's own frames; a second tiny all-gather of the
     per-frame padded-pixel counts completes the meta (padding_fraction_mean/max)
 Outputs stay sharded on the devices.
+
+Motion Apply (`apply_motion_sharded`, BASELINE config C5) needs NO collective: the matrices come from the replicated
+motion_meta JSON, `expand` sizes its canvas from the replicated bounding boxes, `crop` ANDs the coverage of all the
+clip's matrices on every rank (coverage is a function of the matrices only), and a motion-blurred frame at a shard
+edge needs its neighbour's matrix, never its pixels (motion_apply.py:125-134).
 """
 
 from __future__ import annotations
@@ -22,10 +27,11 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import host_math as hm
-from .flow_pipeline import (_ESTIMATORS, complete_meta, resolve_flow_backend, plan_stabilization,
-                            prepare_meta)
+import time
 
+from . import host_math as hm
+from .flow_pipeline import (_ESTIMATORS, _attach_motion_meta, complete_meta, resolve_flow_backend, plan_stabilization,
+                            prepare_meta)
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -37,23 +43,24 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=None) -> np.ndarray:
     """all_gather of equally padded row blocks; returns the concatenation of the valid rows in rank order.
-    One flat receive buffer and one device->host copy (8 per-rank copies cost more than the collective itself)."""
+    One flat receive buffer and one device->host copy (8 per-rank copies cost more than the collective itself).
+    The collective variant is chosen from the backend, never by catching an error: a rank that swallowed a genuine
+    RCCL failure and issued a different collective would desynchronise the group."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    rows = max(counts)
+    rows = max(max(counts), 1)
     padded = np.zeros((rows,) + local.shape[1:], local.dtype)
     padded[: local.shape[0]] = local
     t = torch.from_numpy(padded)
     if device is not None:
         t = t.to(device)
     flat = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    try:
+    if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(flat, t, group=group)
-    except (RuntimeError, NotImplementedError):   # backend without the flat variant
-        bucket = [flat[r] for r in range(world)]
-        dist.all_gather(bucket, t, group=group)
+    else:   # gloo (CPU tests): the list form
+        dist.all_gather([flat[r] for r in range(world)], t, group=group)
     host = flat.cpu().numpy()
     return np.concatenate([host[r, : counts[r]] for r in range(world)], axis=0)
 
@@ -63,8 +70,12 @@ def transition_counts(total_frames: int, world: int) -> List[int]:
     out = []
     for r in range(world):
         s, e = shard_range(total_frames, world, r)
-        out.append((e - s) - (1 if r == 0 else 0))
+        out.append(max(0, (e - s) - (1 if r == 0 else 0)))   # a rank without frames (total < world) has none
     return out
+
+
+def frame_counts(total_frames: int, world: int) -> List[int]:
+    return [shard_range(total_frames, world, r)[1] - shard_range(total_frames, world, r)[0] for r in range(world)]
 
 
 def gather_fit_records(local_table, total_frames: int, group=None, device=None):
@@ -93,20 +104,35 @@ def collective_device(ctx=None):
     return ctx.device if (ctx is not None and dist.get_backend() == "nccl") else None
 
 
+def _lap(stats, key, t0):
+    if stats is not None:
+        stats[key] = stats.get(key, 0.0) + (time.perf_counter() - t0) * 1e3
+    return time.perf_counter()
+
+
 def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, transform_mode: str, camera_lock: bool,
                       strength: float, smooth: float, keep_fov: float, padding_rgb, frame_rate: float, group=None,
-                      estimator: str = "flow"):
+                      estimator: str = "flow", stats: Optional[Dict[str, float]] = None):
     """Sharded equivalent of `_stabilize_frames` (flow.py:213-640).
 
-    local_frames: device tensor [n_local (+1 halo for rank > 0), H, W, 3] float32 -- this rank's frames
-    preceded by the last frame of the previous rank.  Returns (frames [n_local,h,w,3], masks
-    [n_local,h,w], meta) with the outputs resident on this rank's GPU; meta is identical on all ranks."""
+    local_frames: device tensor [n_local (+1 halo for rank > 0 that owns frames), H, W, 3] float32 -- this rank's frames
+    preceded by the last frame of the previous rank; a rank without frames (total_frames < world) passes [0,H,W,3].
+    Returns (frames [n_local,h,w,3], masks [n_local,h,w], meta) with the outputs resident on this rank's GPU; meta is
+    identical on all ranks.  `stats` (optional dict) receives host wall-clock milliseconds per phase of this rank:
+    estimate (launch + the fit's host sync), gather_fits, plan, warp_launch, meta, gather_counts -- the two gathers and
+    plan + meta are the replicated / serial part that bounds strong scaling."""
     import torch.distributed as dist
 
+    from . import native
+
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if total_frames < 2:
+        # flow.py:242-310 (empty / single-frame passthrough) has nothing to shard; every rank raises alike, before
+        # any collective
+        raise ValueError(f"stabilize_sharded needs a clip of at least 2 frames, got {total_frames}")
     start, end = shard_range(total_frames, world, rank)
     n_local = end - start
-    halo = 1 if rank > 0 else 0
+    halo = 1 if (rank > 0 and n_local > 0) else 0
     if local_frames.shape[0] != n_local + halo:
         raise ValueError(f"rank {rank}: got {local_frames.shape[0]} frames, expected {n_local} + {halo} halo")
     height, width = int(local_frames.shape[1]), int(local_frames.shape[2])
@@ -114,25 +140,62 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     fps_effective = float(max(1.0, frame_rate if (isinstance(frame_rate, (int, float)) and np.isfinite(frame_rate) and frame_rate > 0) else 16.0))
     fps_requested = float(frame_rate) if isinstance(frame_rate, (int, float)) and frame_rate > 0.0 else None
     dev = collective_device(ctx)
+    torch = ctx.torch
 
     working_size = hm._working_estimation_size(width, height)
-    from . import native
-
     estimator = resolve_flow_backend(estimator)
     estimate = _ESTIMATORS[estimator]
+    t0 = time.perf_counter()
     local_records = (estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
                      else np.zeros((0, 3), native.FIT_DTYPE))
+    t0 = _lap(stats, "estimate", t0)
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)
+    t0 = _lap(stats, "gather_fits", t0)
     plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
                               keep_fov, padding_rgb, fps_effective, fps_requested, estimator=estimator)
-    if plan.bypass_meta is not None:
-        raise NotImplementedError("crop bypass is not wired into the sharded path")
+    t0 = _lap(stats, "plan", t0)
     own = local_frames[halo:]
-    mats = np.ascontiguousarray(plan.final_matrices[start:end], dtype=np.float32)
-    dst, mask, counts = ctx.warp_batch(own, mats, plan.output_size, interp="bilinear", border=hm.border_value(padding_rgb),
-                                       want_mask=True, want_count=True)
+    if plan.bypass_meta is not None:   # crop + keep_fov ~ 1 (flow.py:387-429): the original frames, zero masks
+        masks = torch.zeros((n_local, height, width), dtype=torch.float32, device=own.device)
+        return own, masks, _attach_motion_meta(plan.bypass_meta, fps_effective, estimator)
+    out_w, out_h = plan.output_size
+    if n_local > 0:
+        mats = np.ascontiguousarray(plan.final_matrices[start:end], dtype=np.float32)
+        dst, mask, counts = ctx.warp_batch(own, mats, plan.output_size, interp="bilinear", border=hm.border_value(padding_rgb),
+                                           want_mask=True, want_count=True)
+    else:   # nothing to warp here, but this rank still takes part in the second collective below
+        dst = torch.empty((0, out_h, out_w, 3), dtype=torch.float32, device=own.device)
+        mask = torch.empty((0, out_h, out_w), dtype=torch.float32, device=own.device)
+        counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
+    t0 = _lap(stats, "warp_launch", t0)
     meta = prepare_meta(plan)  # host JSON work overlaps this rank's warp kernel
-    frame_counts = [shard_range(total_frames, world, r)[1] - shard_range(total_frames, world, r)[0] for r in range(world)]
-    all_counts = _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), frame_counts, group=group, device=dev)
+    t0 = _lap(stats, "meta", t0)
+    all_counts = _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), frame_counts(total_frames, world),
+                              group=group, device=dev)
     meta = complete_meta(meta, plan, all_counts.reshape(-1))
+    _lap(stats, "gather_counts", t0)
     return dst, mask, meta
+
+
+def apply_motion_sharded(ctx, local_frames, start: int, total_frames: int, meta: Dict[str, Any], padding_rgb, *,
+                         framing_mode: str = "crop_and_pad", interpolation: str = "bilinear", motion_blur: float = 0.0,
+                         motion_blur_samples: int = 9, progress_callback=None):
+    """Sharded `apply_motion` (motion_apply.py:297-429): this rank replays frames [start, start + n_local) of a clip of
+    `total_frames` frames whose motion is described by the replicated `meta`.  No collective, no halo frame.
+
+    local_frames: device tensor [n_local, H, W, 3] float32 (may be empty).  Returns (frames [n_local,h,w,3], masks
+    [n_local,h,w], result_meta) on this rank's GPU; result_meta is identical on all ranks.  The validation errors of
+    the reference (size mismatch, frame-count mismatch against the metadata, bad enums) are raised on every rank alike."""
+    from .apply_pipeline import _resolve_motion_for_context, _validate_context, apply_motion_on_device
+
+    n_local = int(local_frames.shape[0])
+    height, width = int(local_frames.shape[1]), int(local_frames.shape[2])
+    if start < 0 or start + n_local > total_frames:
+        raise ValueError(f"shard [{start}, {start + n_local}) lies outside a clip of {total_frames} frames")
+    clip = hm.VideoContext([None] * int(total_frames), hm.FrameAdapter(np.dtype(np.float32), False, "0_1", "torch", False),
+                           width, height, 3, None, "sequence", {})
+    motion = _resolve_motion_for_context(meta, clip)
+    _validate_context(clip, motion)
+    return apply_motion_on_device(ctx, local_frames, int(start), motion, meta, padding_rgb, framing_mode=framing_mode,
+                                  interpolation=interpolation, motion_blur=motion_blur,
+                                  motion_blur_samples=motion_blur_samples, progress_callback=progress_callback)

@@ -111,6 +111,15 @@ _SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     ),
+    "vstab_warp_blur_clip_batch": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+         C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "vstab_blur_sample_matrices": (
+        C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vstab_common_coverage": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_gray_downscale": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_dis_flow_batch": (
@@ -174,6 +183,19 @@ def host_math(op: str, a, b=None) -> np.ndarray:
     bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
     rc = load_library().vstab_host_math(HOST_OPS[op], a.ctypes.data, bb.ctypes.data if bb is not None else None, a.size, out.ctypes.data)
     _check(rc, "vstab_host_math")
+    return out
+
+
+def blur_sample_matrices(matrices64, first: int, count: int, blur: float, samples: int) -> np.ndarray:
+    """The float32 shutter-sample matrices the blur warp uses for frames [first, first+count) of a clip
+    (vstab_blur_sample_matrices; motion_apply.py:125-134 + the cast of :172) -> [count, S', 3, 3] float32."""
+    m = np.ascontiguousarray(matrices64, dtype=np.float64).reshape(-1, 9)
+    ts = np.ascontiguousarray(np.linspace(0.0, float(blur), int(samples), dtype=np.float64))
+    per_frame = 1 if m.shape[0] <= 1 else int(samples)
+    out = np.zeros((int(count), per_frame, 3, 3), np.float32)
+    rc = load_library().vstab_blur_sample_matrices(m.ctypes.data, m.shape[0], int(first), int(count), ts.ctypes.data, int(samples),
+                                                   out.ctypes.data)
+    _check(rc, "vstab_blur_sample_matrices")
     return out
 
 
@@ -276,14 +298,19 @@ class Context:
         return dst, mask, counts
 
     def warp_blur_batch(self, frames, matrices64, out_size, blur, samples, interp="bilinear",
-                        border=(0.0, 0.0, 0.0), subpix=None, want_mask=True, out=None, out_mask=None):
+                        border=(0.0, 0.0, 0.0), subpix=None, want_mask=True, out=None, out_mask=None, clip_first=0):
+        """frames = frames [clip_first, clip_first + n) of the clip whose motion matrices are `matrices64` [total,3,3]
+        (total == n and clip_first == 0 for a whole clip; a shard passes the replicated table of the whole clip)."""
         torch = self.torch
         src = self._as_device_frames(frames)
         n, sh, sw, ch = src.shape
         if ch != 3:
             raise VstabError(f"warp_blur_batch expects 3-channel frames, got {ch}")
         out_w, out_h = int(out_size[0]), int(out_size[1])
-        m = np.ascontiguousarray(matrices64, dtype=np.float64).reshape(n, 9)
+        m = np.ascontiguousarray(matrices64, dtype=np.float64).reshape(-1, 9)
+        total = m.shape[0]
+        if clip_first < 0 or clip_first + n > total:
+            raise VstabError(f"warp_blur_batch: frames [{clip_first}, {clip_first + n}) outside a clip of {total} matrices")
         ts = np.ascontiguousarray(np.linspace(0.0, float(blur), int(samples), dtype=np.float64))
         b = np.ascontiguousarray(border, dtype=np.float32).reshape(3)
         dst = out if out is not None else torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=self.device)
@@ -292,12 +319,12 @@ class Context:
             mask = out_mask if out_mask is not None else torch.empty((n, out_h, out_w), dtype=torch.float32, device=self.device)
         self.use_torch_stream()
         _check(
-            self.lib.vstab_warp_blur_batch(
-                self.handle, _dev_ptr(src), n, sh, sw, m.ctypes.data, ts.ctypes.data, int(samples), out_h, out_w,
-                INTERP[interp], b.ctypes.data, SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst),
+            self.lib.vstab_warp_blur_clip_batch(
+                self.handle, _dev_ptr(src), n, sh, sw, m.ctypes.data, total, int(clip_first), ts.ctypes.data, int(samples),
+                out_h, out_w, INTERP[interp], b.ctypes.data, SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst),
                 _dev_ptr(mask) if mask is not None else None,
             ),
-            "vstab_warp_blur_batch",
+            "vstab_warp_blur_clip_batch",
         )
         return dst, mask
 
@@ -438,6 +465,17 @@ class Context:
         _check(self.lib.vstab_crop_analysis(self.handle, m.ctypes.data, n, sh, sw, oh, ow, bbox.ctypes.data, common.ctypes.data),
                "vstab_crop_analysis")
         return bbox, common
+
+    def common_coverage(self, matrices, src_size, out_size):
+        """AND over frames of the nearest coverage (motion_apply.py:205-227) -> bool [out_h,out_w] on the host."""
+        m = np.ascontiguousarray(matrices, dtype=np.float32).reshape(-1, 9)
+        sw, sh = int(src_size[0]), int(src_size[1])
+        ow, oh = int(out_size[0]), int(out_size[1])
+        common = np.zeros((oh, ow), np.uint8)
+        self.use_torch_stream()
+        _check(self.lib.vstab_common_coverage(self.handle, m.ctypes.data, m.shape[0], sh, sw, oh, ow, common.ctypes.data),
+               "vstab_common_coverage")
+        return common.astype(bool)
 
     def trajectory(self, deltas, smooth, fps, strength, camera_lock):
         d = np.ascontiguousarray(deltas, dtype=np.float64)

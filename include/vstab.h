@@ -12,6 +12,10 @@
  *   - extern "C", plain pointers and sizes, no C++/torch types.
  *   - every call returns 0 on success, non-zero on failure;
  *     vstab_last_error() returns a thread-local message for the last failure.
+ *     A failure detected by a kernel (e.g. an expired dependency wait inside the
+ *     DIS patch search) is recorded in a host-visible status word and reported
+ *     -- return value 3 -- by the next call that synchronises with the host
+ *     (vstab_sample_fit_batch, vstab_synchronize).
  *   - "dev" pointers are HIP device pointers owned by the caller (e.g.
  *     torch.Tensor.data_ptr()); "host" pointers are ordinary host memory.
  *     The library never frees caller memory and never returns owned memory.
@@ -96,6 +100,24 @@ int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, in
                           int out_w, int interp, const float* border_rgb, int subpix,
                           float* dst, float* mask);
 
+/* Shardable form of vstab_warp_blur_batch ("blur needs the next frame's matrix (replicated JSON) but never
+ * another rank's pixels"): src holds frames [clip_first, clip_first + n) of a clip whose motion_meta has clip_total
+ * matrices; clip_matrices is the whole host [clip_total,9] f64 table, so the sample delta of a frame at a shard edge
+ * uses its true neighbour (M[i+1] - M[i]; the clip's last frame: M[i] - M[i-1], motion_apply.py:129-132).
+ * vstab_warp_blur_batch(…, matrices, …) == vstab_warp_blur_clip_batch(…, matrices, n, 0, …). */
+int vstab_warp_blur_clip_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,
+                               const double* clip_matrices, int clip_total, int clip_first,
+                               const double* ts, int samples, int out_h, int out_w, int interp,
+                               const float* border_rgb, int subpix, float* dst, float* mask);
+
+/* ---- A4: the shutter sample matrices themselves (host arithmetic only, no GPU involved) --------
+ * nodes/motion_apply.py:125-134 (_blurred_matrix_samples) followed by the float32 cast of motion_apply.py:172, for
+ * frames [first, first+count) of a clip of `total` f64 matrices: out host [count, S', 9] f32 with S' = samples, or 1
+ * for a single-matrix clip (motion_apply.py:126-127).  This is the routine vstab_warp_blur_*batch runs internally;
+ * exported so that the reference-generated golden vectors pin the shipped arithmetic (tests/test_abi_cpu.py). */
+int vstab_blur_sample_matrices(const double* matrices, int total, int first, int count,
+                               const double* ts, int samples, float* out);
+
 /* ---- F2: grayscale + INTER_AREA downscale to the estimation size ------------
  * Replaces nodes/stabilizer_utils.py:236-242 (_make_gray: cv2.cvtColor RGB2GRAY
  * on f32, clip(gray*255,0,255).astype(uint8)) and :271-276 (cv2.resize INTER_AREA).
@@ -158,6 +180,12 @@ int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, in
  */
 int vstab_crop_analysis(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w,
                         int out_h, int out_w, int32_t* bbox, uint8_t* common);
+
+/* Motion Apply's crop framing (nodes/motion_apply.py:205-227, _common_valid_mask): AND over all frames of
+ * warpPerspective(ones, M, INTER_NEAREST) > 0.5 -- no morphology, no bounding boxes.
+ * matrices host [n,9] f32;  common host [out_h*out_w] u8 (1 = covered by every frame). */
+int vstab_common_coverage(vstab_ctx* ctx, const float* matrices, int n, int src_h, int src_w,
+                          int out_h, int out_w, uint8_t* common);
 
 /* ---- N1 (Classic estimator): sparse features + pyramidal LK ------------------
  * Replaces nodes/video_stabilizer_classic.py:76-96 (`_estimate_motion_pair`) for a whole clip.

@@ -165,6 +165,15 @@ def rgb2gray_u8(rgb, fused_body=True):
     return out
 
 
+def rgb2gray_f32(rgb, fused_body=True):
+    """cv2.cvtColor(rgb f32, COLOR_RGB2GRAY) -> f32 [h,w]."""
+    rgb = _f32(rgb)
+    h, w, _ = rgb.shape
+    out = np.empty((h, w), np.float32)
+    lib().vo_rgb2gray_f32(_ptr(rgb, C.c_float), h, w, 1 if fused_body else 0, _ptr(out, C.c_float))
+    return out
+
+
 def resize_area_u8(src, out_size):
     src = np.ascontiguousarray(src, dtype=np.uint8)
     sh, sw = src.shape
@@ -219,6 +228,33 @@ def dis_flow(i0, i1, params=None):
     if rc != 0:
         raise ValueError(f"vo_dis_calc: unsupported configuration (rc={rc})")
     return flow
+
+
+def dis_flow_stateful(i0, i1, params):
+    """calc() on a persistent DIS object: `params` (DisParams) is updated in place like OpenCV's object state."""
+    i0 = np.ascontiguousarray(i0, dtype=np.uint8)
+    i1 = np.ascontiguousarray(i1, dtype=np.uint8)
+    h, w = i0.shape
+    flow = np.empty((h, w, 2), np.float32)
+    rc = lib().vo_dis_calc_stateful(_ptr(i0, C.c_uint8), _ptr(i1, C.c_uint8), h, w, C.byref(params), _ptr(flow, C.c_float))
+    if rc != 0:
+        raise ValueError(f"vo_dis_calc_stateful: unsupported configuration (rc={rc})")
+    return flow
+
+
+def warp_frame_inv(src, inverse64, out_size, interp="bilinear", border=(0.0, 0.0, 0.0), subpix="q5"):
+    """The warp for a matrix already converted to f64 and inverted (cv2.warpPerspective's internal state after
+    `M.convertTo(CV_64F); invert(M)`): serves callers that pass float64 matrices."""
+    src = _f32(src)
+    sh, sw, _ = src.shape
+    dw, dh = int(out_size[0]), int(out_size[1])
+    inv = np.ascontiguousarray(inverse64, dtype=np.float64).reshape(9)
+    b = _f32(border).reshape(3)
+    dst = np.empty((dh, dw, 3), np.float32)
+    cov = np.empty((dh, dw), np.float32)
+    lib().vo_warp_frame_inv(_ptr(src, C.c_float), sh, sw, _ptr(inv, C.c_double), dh, dw, INTERP[interp], _ptr(b, C.c_float),
+                            SUBPIX[subpix], _ptr(dst, C.c_float), _ptr(cov, C.c_float))
+    return dst, cov
 
 
 def dis_flow_clip(gray, params=None):

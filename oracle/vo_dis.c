@@ -643,6 +643,19 @@ int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis
     return rc;
 }
 
+/* calc() on a persistent DIS object: like vo_dis_calc, and the (possibly auto-selected) finest scale is written back
+ * into *p as OpenCV keeps it in the object -- used by the cv2 stand-in that serves the reference's own pair loop */
+int vo_dis_calc_stateful(const uint8_t* I0, const uint8_t* I1, int h, int w, vo_dis_params* p, float* flow)
+{
+    int coarsest;
+    vo_dis_params probe = *p;
+    int rc = dis_scales(h, w, &probe, &coarsest);
+    if (rc) return rc;
+    rc = vo_dis_calc(I0, I1, h, w, p, flow);
+    if (rc == 0) p->finest_scale = probe.finest_scale;
+    return rc;
+}
+
 static int dis_clip_range(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, int coarsest, float* flow)
 {
     Level* all = (Level*)calloc((size_t)n * MAX_LEVELS, sizeof(Level));

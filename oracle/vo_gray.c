@@ -18,6 +18,20 @@
 #include "vo_common.h"
 #include "vstab_oracle.h"
 
+/* cv2.cvtColor(frame f32, COLOR_RGB2GRAY) on its own (f32 out): what the cv2 stand-in of
+ * tests/golden/cv2_standin.py hands to the reference's `np.clip(gray * 255.0, 0, 255).astype(np.uint8)` */
+void vo_rgb2gray_f32(const float* rgb, int h, int w, int fused_body, float* gray)
+{
+    const float k0 = 0.299f, k1 = 0.587f, k2 = 0.114f;
+    const int body = fused_body ? (w & ~7) : 0;
+    for (int y = 0; y < h; y++) {
+        const float* s = rgb + (size_t)y * w * 3;
+        float* d = gray + (size_t)y * w;
+        for (int x = 0; x < w; x++, s += 3)
+            d[x] = (x < body) ? fmaf(s[2], k2, fmaf(s[1], k1, s[0] * k0)) : s[0] * k0 + s[1] * k1 + s[2] * k2;
+    }
+}
+
 void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray)
 {
     const float k0 = 0.299f, k1 = 0.587f, k2 = 0.114f;

@@ -36,6 +36,7 @@ void vo_crop_analysis(const float* matrices, int n, int sh, int sw, int oh, int 
 
 /* ---- gray + resize (vo_gray.c) ---- */
 void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray);
+void vo_rgb2gray_f32(const float* rgb, int h, int w, int fused_body, float* gray);
 void vo_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 void vo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst, int dh, int dw);
 void vo_gray_for_estimation(const float* rgb, int n, int h, int w, int wh, int ww, int fused_body,
@@ -56,6 +57,7 @@ void vo_dis_default_params(vo_dis_params* p);
 /* I0, I1: u8 [h,w]; flow out: f32 [h,w,2] */
 int vo_dis_calc(const uint8_t* I0, const uint8_t* I1, int h, int w, const vo_dis_params* p,
                 float* flow);
+int vo_dis_calc_stateful(const uint8_t* I0, const uint8_t* I1, int h, int w, vo_dis_params* p, float* flow);
 /* batch over consecutive pairs of a gray clip [n,h,w]; flow [n-1,h,w,2] */
 int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, float* flow);
 int vo_dis_coarsest_scale(int h, int w, int patch_size);

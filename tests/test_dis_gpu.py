@@ -72,3 +72,35 @@ def test_dis_recovers_known_translation(ctx):
     g = grid.cpu().numpy()[0]
     assert g.shape == (68, 120, 2)
     assert abs(np.median(g[..., 0]) - 5.3) < 0.05 and abs(np.median(g[..., 1]) + 2.6) < 0.05
+
+
+def test_expired_dependency_wait_is_reported(pkg):
+    """Fail loudly: when a bounded LDS progress wait of the patch search expires, the kernel records it
+    in the context's host-visible status word and the next synchronising call (the fit) returns non-zero with
+    vstab_last_error() set -- instead of handing back a wrong flow with rc 0.  VSTAB_DEBUG_PIS_SPIN_LIMIT=0 makes every
+    not-yet-satisfied wait expire at once (a debug knob read per call; 960x540 so that the stripes of the finest levels
+    have several rows, i.e. real vertical dependencies).  The status word is cleared by the report, and the same
+    context computes the same flow as before afterwards."""
+    import os
+
+    import torch
+    from vstab_amd import native
+
+    ctx = native.Context()
+    gray, _ = moving_clip(3, 540, 960, seed=7)
+    dev = torch.from_numpy(gray).cuda()
+    _, clean = ctx.dis_flow_batch(dev, sample_step=8)
+    ctx.sample_fit_batch(clean, 8, "similarity")
+    clean = clean.clone()
+    os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"] = "0"
+    try:
+        _, grid = ctx.dis_flow_batch(dev, sample_step=8)
+        with pytest.raises(native.VstabError, match="expired dependency wait"):
+            ctx.sample_fit_batch(grid, 8, "similarity")
+    finally:
+        del os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"]
+    _, grid = ctx.dis_flow_batch(dev, sample_step=8)
+    ctx.sample_fit_batch(grid, 8, "similarity")          # no stale report
+    ctx.synchronize()
+    assert torch.equal(grid, clean)
+    ctx.close()

@@ -106,3 +106,28 @@ def test_trajectory_matches_numpy(ctx, smooth, fps, p, n):
     assert np.allclose(target, ref_target, rtol=0, atol=1e-10)
     _, locked = ctx.trajectory(deltas, smooth, fps, 0.7, True)
     assert np.all(locked == 0.0)
+
+
+def test_trajectory_matches_reference_smooth_golden(ctx):
+    """F8 pinned: the shipped trajectory kernel against the 60 outputs of the REFERENCE's own `_smooth_path`
+    (nodes/stabilizer_utils.py:361-383; tests/golden/reference_helpers.json["smooth"], generated by make_golden.py:95-99
+    from the imported reference).  vstab_trajectory takes per-frame deltas and starts its path at 0, so each golden
+    path is fed as np.diff and its first row is added back; with strength 1 the target IS the smoothed path
+    (flow.py:368: path + 1*(smooth - path)).  Tolerance 1e-12 absolute on values of magnitude <= 30: the golden is
+    np.convolve's summation order, the kernel's is a sequential window sum (observed difference <= 1e-14)."""
+    import json
+    from pathlib import Path
+
+    gold = json.loads((Path(__file__).parent / "golden" / "reference_helpers.json").read_text())
+    paths = {k: np.array(v["__nd__"], dtype=np.float64) for k, v in gold["smooth_paths"].items()}
+    assert len(gold["smooth"]) == 60
+    worst = 0.0
+    for case in gold["smooth"]:
+        path = paths[case["path"]]
+        want = np.array(case["out"]["__nd__"], dtype=np.float64)
+        got_path, target = ctx.trajectory(np.diff(path, axis=0), case["smooth"], case["fps"], 1.0, False)
+        assert np.allclose(got_path + path[0], path, rtol=0, atol=1e-12)
+        err = float(np.max(np.abs(target + path[0] - want)))
+        worst = max(worst, err)
+        assert err <= 1e-12, (case["path"], case["smooth"], case["fps"], err)
+    assert worst <= 1e-12

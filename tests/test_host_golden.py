@@ -87,10 +87,21 @@ def test_expand_matrices_and_blur_samples(pkg, hm):
     em, size = ap._expand_matrices(mats, (192, 108))
     assert np.array_equal(np.stack(em), nd(GOLD["expand_matrices"]["matrices"]))
     assert list(size) == GOLD["expand_matrices"]["size"]
+    # A4: the shipped sample-matrix routine is the library's (vstab_blur_sample_matrices, host arithmetic -- callable
+    # without a GPU); the reference forms the samples in f64 (motion_apply.py:125-134) and casts each to f32 right
+    # before cv2.warpPerspective (motion_apply.py:172): bit-exact after that cast, for every frame position the
+    # golden holds (first / interior / last frame of the clip, single-frame clip)
+    from vstab_amd import native
+
     for case in GOLD["blur_samples"]:
-        got = np.stack(ap._blurred_matrix_samples(mats, case["idx"], case["blur"], case["samples"]))
-        assert np.array_equal(got, nd(case["out"]))
-    assert np.array_equal(np.stack(ap._blurred_matrix_samples(mats[:1], 0, 0.5, 9)), nd(GOLD["blur_single"]))
+        got = native.blur_sample_matrices(np.stack(mats), case["idx"], 1, case["blur"], case["samples"])[0]
+        assert got.dtype == np.float32 and np.array_equal(got, nd(case["out"]).astype(np.float32)), case
+    whole = native.blur_sample_matrices(np.stack(mats), 0, len(mats), 0.5, 17)      # all frames in one call == per frame
+    for case in GOLD["blur_samples"]:
+        if case["samples"] == 17:
+            assert np.array_equal(whole[case["idx"]], nd(case["out"]).astype(np.float32))
+    single = native.blur_sample_matrices(np.stack(mats[:1]), 0, 1, 0.5, 9)
+    assert single.shape == (1, 1, 3, 3) and np.array_equal(single[0], nd(GOLD["blur_single"]).astype(np.float32))
 
 
 def test_padding_color(hm):

@@ -23,7 +23,7 @@ def _clip():
     return np.ascontiguousarray(f)
 
 
-def _worker(rank, world, port, out_dir, estimator):
+def _worker(rank, world, port, out_dir, estimator, framing="expand", keep_fov=0.6, n_frames=9):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -39,12 +39,12 @@ def _worker(rank, world, port, out_dir, estimator):
     try:
         torch.cuda.set_device(0)
         ctx = native.Context(0)
-        frames = _clip()
+        frames = _clip()[:n_frames]
         n = frames.shape[0]
         start, end = vd.shard_range(n, world, rank)
-        halo = 1 if rank > 0 else 0
+        halo = 1 if (rank > 0 and end > start) else 0
         local = torch.from_numpy(frames[start - halo:end]).cuda()
-        dst, mask, meta = vd.stabilize_sharded(ctx, local, n, "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
+        dst, mask, meta = vd.stabilize_sharded(ctx, local, n, framing, "similarity", False, 0.7, 0.5, keep_fov, (127, 127, 127), 16.0,
                                                estimator=estimator)
         np.save(Path(out_dir) / f"dst_{rank}.npy", dst.cpu().numpy())
         np.save(Path(out_dir) / f"mask_{rank}.npy", mask.cpu().numpy())
@@ -55,15 +55,10 @@ def _worker(rank, world, port, out_dir, estimator):
 
 @pytest.mark.parametrize("estimator", ["flow", "classic", "flow_phase_correlate"])
 def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path, estimator):
-    import torch.multiprocessing as mp
-
     from vstab_amd import flow_pipeline as fp
     from vstab_amd import host_math as hm
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), estimator), nprocs=2, join=True)
+    _spawn(2, tmp_path, estimator)
     frames = _clip()
     ref = fp._stabilize_frames(hm._normalize_video_input(frames), "expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
                                estimator=estimator)
@@ -73,3 +68,96 @@ def test_two_rank_shards_equal_single_process(pkg, ctx, tmp_path, estimator):
     want = json.loads(json.dumps(ref.meta))
     for r in range(2):
         assert json.loads((tmp_path / f"meta_{r}.json").read_text()) == want
+
+
+def _spawn(world, tmp_path, *extra):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, str(tmp_path)) + extra, nprocs=world, join=True)
+
+
+def test_rank_without_frames_does_not_hang(pkg, ctx, tmp_path):
+    """total_frames < world left a rank with n_local == 0, whose warp call raised on that rank only
+    while the others blocked in the second all-gather.  3 ranks, 2 frames: rank 2 owns nothing, still joins both
+    collectives, and the concatenated result equals the single-process one."""
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    _spawn(3, tmp_path, "flow", "crop_and_pad", 0.6, 2)
+    frames = _clip()[:2]
+    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6,
+                               (127, 127, 127), 16.0)
+    parts = [np.load(tmp_path / f"dst_{r}.npy") for r in range(3)]
+    assert [p.shape[0] for p in parts] == [1, 1, 0]
+    assert np.array_equal(np.concatenate(parts), ref.frames)
+    want = json.loads(json.dumps(ref.meta))
+    for r in range(3):
+        assert json.loads((tmp_path / f"meta_{r}.json").read_text()) == want
+
+
+def test_sharded_crop_bypass_returns_own_frames(pkg, ctx, tmp_path):
+    """flow.py:387-429 through the sharded driver (was NotImplementedError in round 1): crop + keep_fov 1.0 hands
+    back the original frames, zero masks and the bypass meta, identical to the single-process path."""
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    _spawn(2, tmp_path, "flow", "crop", 1.0, 9)
+    frames = _clip()
+    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "crop", "similarity", False, 0.7, 0.5, 1.0, (127, 127, 127), 16.0)
+    dst = np.concatenate([np.load(tmp_path / f"dst_{r}.npy") for r in range(2)])
+    mask = np.concatenate([np.load(tmp_path / f"mask_{r}.npy") for r in range(2)])
+    assert np.array_equal(dst, frames) and np.array_equal(dst, ref.frames) and not mask.any()
+    want = json.loads(json.dumps(ref.meta))
+    assert want["note"].startswith("keep_fov~=1.0")
+    for r in range(2):
+        assert json.loads((tmp_path / f"meta_{r}.json").read_text()) == want
+
+
+@pytest.mark.parametrize("framing,interp,blur,samples", [("expand", "bilinear", 0.5, 33), ("crop_and_pad", "bicubic", 0.5, 17),
+                                                         ("crop", "bilinear", 0.3, 5), ("expand", "bicubic", 0.0, 9)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_motion_apply_equals_single_process(pkg, ctx, framing, interp, blur, samples, world):
+    """BASELINE config C5's missing piece: Motion Apply over frame shards.  No process group is involved
+    -- the path has no collective -- so the shards are replayed one after the other on this GPU: their concatenation
+    must equal apply_motion on the whole clip bit for bit, including the blurred frames at the shard edges (whose
+    sample delta uses the neighbour rank's matrix, motion_apply.py:125-134) and the clip's last frame (backward delta),
+    the expand canvas and the crop matrix (clip-global), and the result meta."""
+    import torch
+
+    from vstab_amd import apply_pipeline as ap
+    from vstab_amd import distributed as vd
+    from vstab_amd import host_math as hm
+    from vstab_amd import meta_v2 as mv
+    from tests.util import synth_frames, test_matrices
+
+    n, h, w = 7, 90, 120
+    frames = synth_frames(n, h, w, seed=3)
+    mats = test_matrices(n, w, h, "perspective" if framing != "crop" else "translation", seed=11)
+    if framing == "crop":
+        mats = [np.array([[1, 0, 0.6 * m[0, 2]], [0, 1, 0.6 * m[1, 2]], [0, 0, 1.0]]) for m in mats]
+    meta = {"motion_meta": mv.build_motion_meta_v2(source="manual", frame_count=n, fps=16.0, input_size=(w, h), output_size=(w, h),
+                                                   matrices=list(mats))}
+    kw = dict(framing_mode=framing, interpolation=interp, motion_blur=blur, motion_blur_samples=samples)
+    ticks_ref = []
+    ref = ap.apply_motion(hm._normalize_video_input(frames), meta, (10, 200, 30), progress_callback=lambda: ticks_ref.append(1), **kw)
+    parts, masks, ticks = [], [], []
+    for rank in range(world):
+        s, e = vd.shard_range(n, world, rank)
+        f, m, rmeta = vd.apply_motion_sharded(ctx, torch.from_numpy(frames[s:e]).cuda(), s, n, meta, (10, 200, 30),
+                                              progress_callback=lambda: ticks.append(1), **kw)
+        parts.append(f.cpu().numpy())
+        masks.append(m.cpu().numpy())
+        assert json.loads(json.dumps(rmeta)) == json.loads(json.dumps(ref.meta))
+    assert np.array_equal(np.concatenate(parts), ref.frames)
+    assert np.array_equal(np.concatenate(masks), ref.masks[..., 0])
+    assert len(ticks) == len(ticks_ref)
+    if framing == "crop":
+        assert "framing_fallback" not in ref.meta and not ref.masks.any()
+    # an empty shard (clip shorter than the world) yields empty tensors of the right geometry and the same meta
+    f, m, rmeta = vd.apply_motion_sharded(ctx, torch.from_numpy(frames[n:n]).cuda(), n, n, meta, (10, 200, 30), **kw)
+    assert f.shape[0] == 0 and tuple(f.shape[1:]) == ref.frames.shape[1:] and json.loads(json.dumps(rmeta)) == json.loads(json.dumps(ref.meta))
+    with pytest.raises(ValueError, match="Frame count mismatch"):
+        vd.apply_motion_sharded(ctx, torch.from_numpy(frames[:3]).cuda(), 0, n + 1, meta, (10, 200, 30), **kw)
