@@ -225,27 +225,72 @@ __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ 
 }
 
 // ---- patch inverse search ------------------------------------------------------------------
-// 64-lane sum in the XOR-butterfly association (pairs, quads, 8-groups, 16-rows, row pairs, halves) done
-// with DPP row operations instead of LDS-path shuffles; every level adds the same two partial sums the
-// butterfly would, so the result is bit-identical to oracle/vo_dis.c's butterfly64().  Total lands in lane 63.
+// The four per-patch sums (sum d, sum d^2, sum d*Ix, sum d*Iy over the 8x8 patch) in OpenCV's own f32 association
+// (video/src/dis_flow.cpp, CV_SIMD128 branch of processPatchMeanNorm / computeSSDMeanNorm, patch size 8): one
+// 4-lane accumulator; row after row adds (left half + right half) of its 8 terms -- accumulator lane l collects
+// columns l and l+4 -- and v_reduce_sum folds the lanes as (a0 + a2) + (a1 + a3).  These sums feed the branches
+// `SSD >= prev_SSD` and `cur_SSD < min_SSD`, where a last-bit difference moves a patch by a whole descent step
+// (round 1 used an XOR butterfly here; measured against this order it changed 0.4 % of the sampled flow vectors by
+// more than 1e-3 px, profiles/r02_dis_sum_order.md), so the association is part of the arithmetic contract.
+//
+// Mapping: a patch lives in one half-wave (32 lanes); lane (r, l) = 4*r + l holds the patch pixels (r, l) and
+// (r, l+4), so "left + right" is an in-lane add; the rows of accumulator lane l sit 4 lanes apart = one DPP bank
+// apart: acc_r = acc_(r-1) + s_r is one bank-masked `row_shr:4` DPP add per row, in row order.  Patch rows 0-3 are
+// DPP row 0 (2 for the upper half-wave), rows 4-7 DPP row 1 (3): the hop from lanes 12-15 to lanes 16-19 goes
+// through v_permlane16_swap (vdst row 1 <- src row 0) + a `row_ror:4` add.  The fold is two quad_perm adds.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_sum(float v)
+
+// one chain step on N independent sums: x[bank] += x[bank - 1] for the lanes of ROWMASK/BANKMASK only
+#define VSTAB_DPP_STEP(INSN_TAIL)                                                                             \
+    if constexpr (N == 4)                                                                                     \
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " INSN_TAIL "\n\tv_add_f32_dpp %1, %1, %1 " INSN_TAIL              \
+            "\n\tv_add_f32_dpp %2, %2, %2 " INSN_TAIL "\n\tv_add_f32_dpp %3, %3, %3 " INSN_TAIL                     \
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));                                                \
+    else                                                                                                      \
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " INSN_TAIL "\n\tv_add_f32_dpp %1, %1, %1 " INSN_TAIL              \
+            : "+v"(x[0]), "+v"(x[1]))
+
+// x[k] = this lane's (left + right) term of sum k; on return every lane holds its own patch's totals
+template <int N>
+__device__ __forceinline__ void patch_sums(float (&x)[N])
 {
-    v += dpp_fetch<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v += dpp_fetch<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v += dpp_fetch<0x141, 0xf>(v);   // row_half_mirror
-    v += dpp_fetch<0x140, 0xf>(v);   // row_mirror
-    // row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3 as single DPP adds that leave the other rows untouched
-    // (the builtin form needs a zero-filled temporary and a separate add: 8 of the ~105 instructions of a
-    // gradient-descent step, and this kernel is VALU-bound).  Only lane 63, which both steps write, is read below.
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    static_assert(N == 2 || N == 4, "two sums for an SSD evaluation, four for a descent step");
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x2");   // acc_1 = acc_0 + s_1   (acc_0 = 0 + s_0 = s_0)
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x4");   // acc_2
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x8");   // acc_3
+    float t[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {   // DPP row 1 (3) of t <- DPP row 0 (2) of x
+        const unsigned u = __builtin_bit_cast(unsigned, x[k]);
+        t[k] = __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(u, u, false, false)[0]);
+    }
+    if constexpr (N == 4)                                      // acc_4 = acc_3 + s_4: lanes 16-19 <- lanes 12-15
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %4, %0 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %1, %5, %1 row_ror:4 row_mask:0xa bank_mask:0x1"
+            "\n\tv_add_f32_dpp %2, %6, %2 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %3, %7, %3 row_ror:4 row_mask:0xa bank_mask:0x1"
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %0 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %1, %3, %1 row_ror:4 row_mask:0xa bank_mask:0x1"
+            : "+v"(x[0]), "+v"(x[1]) : "v"(t[0]), "v"(t[1]));
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x2");   // acc_5
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x4");   // acc_6
+    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x8");   // acc_7: lanes 28-31 (60-63) hold a0..a3
+    VSTAB_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xa bank_mask:0x8");   // a0+a2, a1+a3, (a2+a0, a3+a1)
+    VSTAB_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xa bank_mask:0x8");   // (a0+a2) + (a1+a3) in all four lanes
+    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU
+    // instructions on the critical path of the gradient descent; a ds_bpermute is an LDS round trip
+    const bool upper = (__lane_id() & 32) != 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[k]), 31));
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[k]), 63));
+        x[k] = upper ? t1 : t0;
+    }
 }
+#undef VSTAB_DPP_STEP
 
 struct Bilin { int off; float w00, w01, w10, w11; };
 
@@ -267,14 +312,7 @@ __device__ __forceinline__ Bilin bilin_weights(int i, int j, float Ux, float Uy,
     return b;
 }
 
-#ifdef VSTAB_PIS_TRACE   // developer build: per-wave start/end stamps (tools/pis_residency.py)
-static long long* g_pis_dbg = nullptr;
-extern "C" void vstab_pis_dbg(long long* p) { g_pis_dbg = p; }
-#endif
 struct PisArgs {
-#ifdef VSTAB_PIS_TRACE
-    long long* dbg;
-#endif
     const uint8_t* I;      // [n][h][w]
     const uint8_t* Iext;   // [n][h+32][w+32]
     const short* Ix;       // [n][h][w]
@@ -312,180 +350,12 @@ __device__ __forceinline__ void wait_progress(volatile int* counter, int need, i
         __hip_atomic_fetch_or(status, VSTAB_STATUS_PIS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Residency: the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) waves per SIMD, i.e. 8 only up to 80 SGPRs
-// (MI355X_MICROARCH.md, 'Residency'); unconstrained the compiler takes 100 and the 2 x P workgroups of a clip ran in
-// two rounds (tools/pis_residency.py: 254 of 510 started 0.8 ms late).  With the cap all are co-resident.  The gain
-// is small (5.95 -> 5.85 ms DIS per clip) because the kernel is VALU-bound either way: PMC SQ_ACTIVE_INST_VALU =
-// 7.3e8 wave-instructions x 4 cycles / 1024 SIMDs = 74 % of the launch.
-template <int PIS_ROW_WAVES>
-__global__ __launch_bounds__(256 * PIS_ROW_WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void pis_kernel(PisArgs a)
-{
-    extern __shared__ unsigned char pis_lds[];
-    const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
-    const int stripe = half * PIS_STRIPES_PER_BLOCK + wave / PIS_ROW_WAVES, rlane = wave % PIS_ROW_WAVES;
-    const int w = a.w, h = a.h, ws = a.ws, hs = a.hs;
-    const int w_ext = w + 2 * DIS_BORDER, h_ext = h + 2 * DIS_BORDER;
-    const int img_bytes = (w_ext * h_ext + 15) & ~15;
-    unsigned char* lI1 = pis_lds;
-    float* lSx = reinterpret_cast<float*>(pis_lds + img_bytes);   // [hs][ws] (only this block's stripes are used)
-    float* lSy = lSx + hs * ws;
-    int* done0 = reinterpret_cast<int*>(lSy + hs * ws);            // [hs] patches finished in the forward pass
-    int* done1 = done0 + hs;                                       // [hs] ... in the backward pass
-    {
-        const unsigned char* sb = a.Iext + (size_t)(pair + 1) * h_ext * w_ext;
-        const bool aligned = ((reinterpret_cast<uintptr_t>(sb) & 15) == 0);
-        const int nvec = aligned ? (w_ext * h_ext) / 16 : 0;
-        const uint4* src = reinterpret_cast<const uint4*>(sb);
-        uint4* dst = reinterpret_cast<uint4*>(lI1);
-        for (int k = threadIdx.x; k < nvec; k += blockDim.x) dst[k] = src[k];
-        for (int k = nvec * 16 + threadIdx.x; k < w_ext * h_ext; k += blockDim.x) lI1[k] = sb[k];
-        for (int k = threadIdx.x; k < 2 * hs; k += blockDim.x) done0[k] = 0;
-    }
-    __syncthreads();
-    const int row_lo = min(stripe * a.stripe_sz, hs), row_hi = min((stripe + 1) * a.stripe_sz, hs);
-    const uint8_t* I0 = a.I + (size_t)pair * h * w;
-    const short* Ix = a.Ix + (size_t)pair * h * w;
-    const short* Iy = a.Iy + (size_t)pair * h * w;
-    const size_t tplane = (size_t)a.n * hs * ws;
-    const float* T = a.tensor + (size_t)pair * hs * ws;
-    const float* U = a.U + (size_t)pair * h * w;
-    const float* V = a.V + (size_t)pair * h * w;
-    const float i_lo = DIS_BORDER - PSZ + 1.0f, i_hi = DIS_BORDER + h - 1.0f;
-    const float j_lo = DIS_BORDER - PSZ + 1.0f, j_hi = DIS_BORDER + w - 1.0f;
-    const int num_inner_iter = GD_ITERS / 2;
-#ifdef VSTAB_PIS_TRACE
-    const long long t_begin = wall_clock64();
-#endif
-    const float nn = (float)(PSZ * PSZ);
-    const int lane_off1 = r * w_ext + c;
-
-    for (int iter = 0; iter < 2; iter++) {
-        const int dir = (iter == 0) ? 1 : -1;
-        const int start_is = (iter == 0) ? row_lo : row_hi - 1;
-        const int end_is = (iter == 0) ? row_hi : row_lo - 1;
-        const int start_js = (iter == 0) ? 0 : ws - 1;
-        const int end_js = (iter == 0) ? ws : -1;
-        volatile int* done = (iter == 0) ? done0 : done1;
-        for (int is = start_is; dir * is < dir * end_is; is += dir) {
-            if (((is - row_lo) % PIS_ROW_WAVES) != rlane) continue;   // rows of the stripe are dealt round-robin to its waves
-            const bool has_vert = dir * is > dir * start_is;           // a previously visited row exists in this pass
-            const int i = is * PSTR;
-            int visited = 0;
-            for (int js = start_js; dir * js < dir * end_js; js += dir, visited++) {
-                const int j = js * PSTR;
-                const int sidx = is * ws + js;
-                const size_t poff = (size_t)(i + r) * w + j + c;
-                const float i0 = (float)I0[poff];
-                const float gx = (float)Ix[poff], gy = (float)Iy[poff];
-                const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
-                const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
-                float Sxv, Syv;
-                if (iter == 0) {
-                    Sxv = U[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
-                    Syv = V[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
-                } else {
-                    Sxv = lSx[sidx];
-                    Syv = lSy[sidx];
-                }
-#define PATCH_DIFF(bw)                                                                                     \
-    ({                                                                                                     \
-        const unsigned char* q_ = lI1 + (bw).off + lane_off1;                                              \
-        (bw).w00 * (float)q_[0] + (bw).w01 * (float)q_[1] + (bw).w10 * (float)q_[w_ext] +                  \
-            (bw).w11 * (float)q_[w_ext + 1] - i0;                                                          \
-    })
-#define SSD_AT(dst, ux, uy)                                                                                \
-    do {                                                                                                   \
-        Bilin b_ = bilin_weights(i, j, (ux), (uy), i_lo, i_hi, j_lo, j_hi, w_ext);                         \
-        const float d_ = PATCH_DIFF(b_);                                                                   \
-        const float sd_ = wave_sum(d_), sq_ = wave_sum(d_ * d_);                                           \
-        dst = sq_ - sd_ * sd_ / nn;                                                                        \
-    } while (0)
-                float min_SSD, cur_SSD;
-                SSD_AT(min_SSD, Sxv, Syv);
-                if (dir * js > dir * start_js) {
-                    const float nx = lSx[sidx - dir], ny = lSy[sidx - dir];
-                    SSD_AT(cur_SSD, nx, ny);
-                    if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
-                }
-                if (has_vert) {
-                    wait_progress(done + (is - dir), visited + 1, a.spin_limit, a.status);   // the row above/below has finished this column
-                    const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
-                    SSD_AT(cur_SSD, nx, ny);
-                    if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
-                }
-                float cur_Ux = Sxv, cur_Uy = Syv;
-                float detH = txx * tyy - txy * txy;
-                if (__builtin_fabsf(detH) < DIS_EPS) detH = DIS_EPS;
-                const float invH11 = tyy / detH, invH12 = -txy / detH, invH22 = txx / detH;
-                float prev_SSD = DIS_INF;
-                for (int t = 0; t < num_inner_iter; t++) {
-                    Bilin b = bilin_weights(i, j, cur_Ux, cur_Uy, i_lo, i_hi, j_lo, j_hi, w_ext);
-                    const float d = PATCH_DIFF(b);
-                    const float sum_diff = wave_sum(d), sum_sq = wave_sum(d * d);
-                    const float sum_x = wave_sum(d * gx), sum_y = wave_sum(d * gy);
-                    const float dUx = sum_x - sum_diff * x_grad_sum / nn;
-                    const float dUy = sum_y - sum_diff * y_grad_sum / nn;
-                    const float SSD = sum_sq - sum_diff * sum_diff / nn;
-                    const float dx = invH11 * dUx + invH12 * dUy;
-                    const float dy = invH12 * dUx + invH22 * dUy;
-                    cur_Ux -= dx;
-                    cur_Uy -= dy;
-                    if (SSD >= prev_SSD) break;
-                    prev_SSD = SSD;
-                }
-#undef SSD_AT
-#undef PATCH_DIFF
-                {
-                    const double ddx = (double)(cur_Ux - Sxv), ddy = (double)(cur_Uy - Syv);
-                    if (__builtin_sqrt(ddx * ddx + ddy * ddy) <= (double)PSZ) { Sxv = cur_Ux; Syv = cur_Uy; }
-                }
-                if (lane == 0) {
-                    lSx[sidx] = Sxv;
-                    lSy[sidx] = Syv;
-                    __hip_atomic_store(const_cast<int*>(done + is), visited + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-#ifdef VSTAB_PIS_TRACE
-    if (a.dbg && lane == 0) { long long* o = a.dbg + ((size_t)blockIdx.x * 16 + wave) * 2; o[0] = t_begin; o[1] = wall_clock64(); }
-#endif
-    __syncthreads();
-    // this block's stripes only
-    const int blk_lo = min(half * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
-    const int blk_hi = min((half + 1) * PIS_STRIPES_PER_BLOCK * a.stripe_sz, hs);
-    float* Sx = a.Sx + (size_t)pair * hs * ws;
-    float* Sy = a.Sy + (size_t)pair * hs * ws;
-    for (int k = blk_lo * ws + threadIdx.x; k < blk_hi * ws; k += blockDim.x) { Sx[k] = lSx[k]; Sy[k] = lSy[k]; }
-}
-
 // ---- patch inverse search, two patch rows per wavefront ----------------------------------------
-// Same algorithm and the same arithmetic as pis_kernel, other mapping: a wavefront holds TWO 8x8 patches (lanes
-// 0-31 and 32-63, two horizontally adjacent pixels per lane) of two consecutive patch rows of a stripe; the second
-// row trails the first by one patch, which is exactly the raster dependency (left neighbour = own previous patch,
-// vertical neighbour = the other half's previous patch).  The weight / update arithmetic that is uniform over a
-// patch is issued once for both patches, so the VALU work per patch -- the bound of pis_kernel -- nearly halves;
-// half as many wavefronts carry the same chains.  The 64-pixel sums keep the butterfly association of wave_sum():
-// in-lane pair, quad_perm x2 (columns), row_half_mirror, row_mirror, row_bcast15 (rows), every level adding the same
-// two partial sums, so the totals (lane 31 / lane 63 of the halves) are bit-identical.
-
-__device__ __forceinline__ float half_sum(float v0, float v1)
-{
-    float v = v0 + v1;
-    v += dpp_fetch<0xB1, 0xf>(v);
-    v += dpp_fetch<0x4E, 0xf>(v);
-    v += dpp_fetch<0x141, 0xf>(v);
-    v += dpp_fetch<0x140, 0xf>(v);
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU
-    // instructions on the critical path of the gradient descent; a ds_bpermute is an LDS round trip
-    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
-    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-    return (__lane_id() & 32) ? t1 : t0;
-}
+// A wavefront holds TWO 8x8 patches (lanes 0-31 and 32-63; lane (r, l) of a half owns the pixels (r, l) and (r, l+4),
+// see patch_sums above) of two consecutive patch rows of a stripe; the second row trails the first by one patch,
+// which is exactly the raster dependency (left neighbour = own previous patch, vertical neighbour = the other half's
+// previous patch).  The weight / update arithmetic that is uniform over a patch is issued once for both patches.
+// Single-row stripes (coarsest levels, tiny images) run the same kernel with the upper half idle.
 
 // PIS2_PAIR_WAVES wavefronts per stripe share its row pairs round-robin (2 where a stripe has 3-4 rows, 1 for 2 rows).
 template <int PIS2_PAIR_WAVES>
@@ -528,7 +398,7 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
     const float j_lo = DIS_BORDER - PSZ + 1.0f, j_hi = DIS_BORDER + w - 1.0f;
     const int num_inner_iter = GD_ITERS / 2;
     const float nn = (float)(PSZ * PSZ);
-    const int lane_off2 = r * w_ext + 2 * c2;
+    const int lane_off2 = r * w_ext + c2;
 
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
@@ -555,10 +425,10 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                     const int js = start_js + dir * visited;
                     const int j = js * PSTR;
                     const int sidx = is * ws + js;
-                    const size_t poff = (size_t)(i + r) * w + j + 2 * c2;
-                    const float i0a = (float)I0[poff], i0b = (float)I0[poff + 1];
-                    const float gxa = (float)Ix[poff], gxb = (float)Ix[poff + 1];
-                    const float gya = (float)Iy[poff], gyb = (float)Iy[poff + 1];
+                    const size_t poff = (size_t)(i + r) * w + j + c2;     // columns c2 and c2 + 4 of patch row r
+                    const float i0a = (float)I0[poff], i0b = (float)I0[poff + 4];
+                    const float gxa = (float)Ix[poff], gxb = (float)Ix[poff + 4];
+                    const float gya = (float)Iy[poff], gyb = (float)Iy[poff + 4];
                     const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
                     const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
                     float Sxv, Syv;
@@ -572,18 +442,20 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
 #define PATCH_DIFF2(bw, d0_, d1_)                                                                          \
     do {                                                                                                   \
         const unsigned char* q_ = lI1 + (bw).off + lane_off2;                                              \
-        const float q00_ = (float)q_[0], q01_ = (float)q_[1], q02_ = (float)q_[2];                         \
-        const float q10_ = (float)q_[w_ext], q11_ = (float)q_[w_ext + 1], q12_ = (float)q_[w_ext + 2];     \
+        const float q00_ = (float)q_[0], q01_ = (float)q_[1], q04_ = (float)q_[4], q05_ = (float)q_[5];    \
+        const float q10_ = (float)q_[w_ext], q11_ = (float)q_[w_ext + 1];                                  \
+        const float q14_ = (float)q_[w_ext + 4], q15_ = (float)q_[w_ext + 5];                              \
         d0_ = (bw).w00 * q00_ + (bw).w01 * q01_ + (bw).w10 * q10_ + (bw).w11 * q11_ - i0a;                 \
-        d1_ = (bw).w00 * q01_ + (bw).w01 * q02_ + (bw).w10 * q11_ + (bw).w11 * q12_ - i0b;                 \
+        d1_ = (bw).w00 * q04_ + (bw).w01 * q05_ + (bw).w10 * q14_ + (bw).w11 * q15_ - i0b;                 \
     } while (0)
 #define SSD_AT2(dst, ux, uy)                                                                               \
     do {                                                                                                   \
         Bilin b_ = bilin_weights(i, j, (ux), (uy), i_lo, i_hi, j_lo, j_hi, w_ext);                         \
         float e0_, e1_;                                                                                    \
         PATCH_DIFF2(b_, e0_, e1_);                                                                         \
-        const float sd_ = half_sum(e0_, e1_), sq_ = half_sum(e0_ * e0_, e1_ * e1_);          \
-        dst = sq_ - sd_ * sd_ / nn;                                                                        \
+        float ps_[2] = {e0_ + e1_, e0_ * e0_ + e1_ * e1_};                                                 \
+        patch_sums<2>(ps_);                                                                                \
+        dst = ps_[1] - ps_[0] * ps_[0] / nn;                                                               \
     } while (0)
                     float min_SSD, cur_SSD;
                     SSD_AT2(min_SSD, Sxv, Syv);
@@ -606,8 +478,9 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                         Bilin b = bilin_weights(i, j, cur_Ux, cur_Uy, i_lo, i_hi, j_lo, j_hi, w_ext);
                         float d0, d1;
                         PATCH_DIFF2(b, d0, d1);
-                        const float sum_diff = half_sum(d0, d1), sum_sq = half_sum(d0 * d0, d1 * d1);
-                        const float sum_x = half_sum(d0 * gxa, d1 * gxb), sum_y = half_sum(d0 * gya, d1 * gyb);
+                        float ps[4] = {d0 + d1, d0 * d0 + d1 * d1, d0 * gxa + d1 * gxb, d0 * gya + d1 * gyb};
+                        patch_sums<4>(ps);
+                        const float sum_diff = ps[0], sum_sq = ps[1], sum_x = ps[2], sum_y = ps[3];
                         const float dUx = sum_x - sum_diff * x_grad_sum / nn;
                         const float dUy = sum_y - sum_diff * y_grad_sum / nn;
                         const float SSD = sum_sq - sum_diff * sum_diff / nn;
@@ -1190,9 +1063,6 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
         PisArgs pa{};
-#ifdef VSTAB_PIS_TRACE
-        pa.dbg = (i == FINEST) ? g_pis_dbg : nullptr;
-#endif
         pa.I = I[i]; pa.Iext = Iext[i]; pa.Ix = Ixs[i]; pa.Iy = Iys[i]; pa.tensor = tensor[i];
         pa.U = Ul[i]; pa.V = Vl[i]; pa.Sx = Sx; pa.Sy = Sy;
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
@@ -1202,24 +1072,15 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.status = ctx->d_status;
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
-        // rows of a stripe are pipelined over 4 waves only where a stripe has enough rows to pay for it
-        static const bool use_pis2 = !(getenv("VSTAB_PIS2") && atoi(getenv("VSTAB_PIS2")) == 0);
-        if (pa.stripe_sz >= 3 && use_pis2) {
+        // two wavefronts per stripe share its row pairs where a stripe has 3-4 rows, one otherwise
+        if (pa.stripe_sz >= 3) {
             if (lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL(pis2_kernel<2>, dim3((unsigned)P * 2), dim3(64 * 2 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
-        } else if (pa.stripe_sz == 2 && use_pis2) {
+        } else {
             if (lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL(pis2_kernel<1>, dim3((unsigned)P * 2), dim3(64 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
-        } else if (pa.stripe_sz >= 3) {
-            if (lds_bytes > 64 * 1024)
-                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(pis_kernel<4>, dim3((unsigned)P * 2), dim3(1024), lds_bytes, st, pa);
-        } else {
-            if (lds_bytes > 64 * 1024)
-                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(pis_kernel<1>, dim3((unsigned)P * 2), dim3(256), lds_bytes, st, pa);
         }
         LevelArgs la{};
 #ifdef VSTAB_FUSED_TRACE

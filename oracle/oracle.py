@@ -230,6 +230,23 @@ def dis_flow(i0, i1, params=None):
     return flow
 
 
+class dis_sum_order:
+    """with dis_sum_order("butterfly"): ... -- the four patch sums of the inverse search use the XOR butterfly that
+    round 1 shipped instead of OpenCV's SIMD128 row accumulators (the default, which the HIP kernel reproduces);
+    deviation measurement only (vo_dis.c)."""
+
+    def __init__(self, order):
+        self.order = {"butterfly": 0, "opencv": 1}[order]
+
+    def __enter__(self):
+        self.prev = lib().vo_dis_get_sum_order()
+        lib().vo_dis_set_sum_order(self.order)
+
+    def __exit__(self, *exc):
+        lib().vo_dis_set_sum_order(self.prev)
+        return False
+
+
 def dis_flow_stateful(i0, i1, params):
     """calc() on a persistent DIS object: `params` (DisParams) is updated in place like OpenCV's object state."""
     i0 = np.ascontiguousarray(i0, dtype=np.uint8)

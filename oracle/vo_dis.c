@@ -210,7 +210,7 @@ static void build_levels(const uint8_t* gray, int h, int w, const vo_dis_params*
     }
 }
 
-/* 64-element XOR-butterfly sum (wavefront shuffle reduction order) */
+/* 64-element XOR-butterfly sum (wavefront shuffle reduction order; round-1 association, measurement only) */
 static inline float butterfly64(float* v)
 {
     float t[64];
@@ -220,6 +220,28 @@ static inline float butterfly64(float* v)
     }
     return v[0];
 }
+
+/* OpenCV's own association for patch size 8 (video/src/dis_flow.cpp, processPatchMeanNorm / computeSSDMeanNorm,
+ * CV_SIMD128 branch): one v_float32x4 accumulator per sum; every row adds (left half + right half) of its 8 terms to
+ * it -- lane l collects columns l and l+4, rows in order -- and v_reduce_sum folds the four lanes as
+ * (a0 + a2) + (a1 + a3) (the SSE implementation: add the upper half onto the lower, then lane 1 onto lane 0).
+ * The per-element terms (d, d*d, d*Ix, d*Iy) are the same f32 values in both orders. */
+static inline float opencv_rows4_sum(const float* t)
+{
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 8; r++)
+        for (int l = 0; l < 4; l++) acc[l] = acc[l] + (t[r * 8 + l] + t[r * 8 + l + 4]);
+    return (acc[0] + acc[2]) + (acc[1] + acc[3]);
+}
+
+/* 1 (default): OpenCV's 4-lane row accumulators -- the definition; the HIP kernel reproduces it lane for lane.
+ * 0: the XOR butterfly round 1 shipped (a plain wavefront shuffle reduction).  Kept only so that
+ *    tests/test_dis_sum_order_cpu.py can keep measuring what that shortcut cost: the two orders differ in the last
+ *    bit of a sum, a branch of the descent flips, and a few sampled flow vectors move by 1e-3 .. 2e-2 px. */
+static int g_sum_order = 1;
+void vo_dis_set_sum_order(int order) { g_sum_order = order ? 1 : 0; }
+int vo_dis_get_sum_order(void) { return g_sum_order; }
+static inline float patch_sum(float* v) { return g_sum_order ? opencv_rows4_sum(v) : butterfly64(v); }
 
 typedef struct { float sum_diff, sum_sq, sum_x, sum_y; } PatchSums;
 
@@ -242,10 +264,10 @@ static PatchSums patch_eval(const uint8_t* I0p, int s0, const uint8_t* I1p, int 
             }
         }
     PatchSums s;
-    s.sum_diff = butterfly64(d);
-    s.sum_sq = butterfly64(d2);
-    s.sum_x = grad ? butterfly64(dx) : 0.f;
-    s.sum_y = grad ? butterfly64(dy) : 0.f;
+    s.sum_diff = patch_sum(d);
+    s.sum_sq = patch_sum(d2);
+    s.sum_x = grad ? patch_sum(dx) : 0.f;
+    s.sum_y = grad ? patch_sum(dy) : 0.f;
     return s;
 }
 

@@ -61,6 +61,10 @@ int vo_dis_calc_stateful(const uint8_t* I0, const uint8_t* I1, int h, int w, vo_
 /* batch over consecutive pairs of a gray clip [n,h,w]; flow [n-1,h,w,2] */
 int vo_dis_calc_clip(const uint8_t* gray, int n, int h, int w, const vo_dis_params* p, float* flow);
 int vo_dis_coarsest_scale(int h, int w, int patch_size);
+/* association of the four 8x8 patch sums: 1 = OpenCV's SIMD128 row accumulators (default; what the HIP kernel does),
+ * 0 = the XOR butterfly of round 1 (deviation measurement only).  Process-global; set before calling vo_dis_calc*. */
+void vo_dis_set_sum_order(int order);
+int vo_dis_get_sum_order(void);
 
 /* ---- sampling + model fit (vo_fit.c) ---- */
 typedef struct vo_fit_result {
