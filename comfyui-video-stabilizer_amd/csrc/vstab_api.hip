@@ -162,6 +162,7 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->d_fit.release();
     ctx->h_fit.release();
     ctx->d_gray_tmp.release();
+    ctx->d_range.release();
     for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
     if (ctx->h_status) (void)hipHostFree(const_cast<int*>(ctx->h_status));

@@ -36,13 +36,23 @@ __device__ __forceinline__ int sat_u8_round(float v)
 // One workgroup per output row; thread t produces the pixels t, t + 256, ...: the lanes of a wavefront read
 // CONSECUTIVE K-pixel groups (K * 12 B apart), so one load instruction touches K * 12 * 64 contiguous bytes
 // instead of 64 scattered 16-B pieces (the texture addresser, not HBM, was the limit with 4 pixels per thread).
-template <int K>
+//
+// RANGE: the same pass also yields the largest sample of every source row it reads (NaN if the row holds one, as
+// numpy's max does) -- the value-range sniff of nodes/stabilizer_utils.py:127-131 (`float(arr.max()) > 1.5` per frame)
+// for free, instead of a second 24.9 MB read per frame.  Written per block to row_max[f * dh + y]; only valid when the
+// K x K boxes tile the whole source (the host checks dh * K == sh and dw * K == sw).
+template <int K, bool RANGE>
 __global__ __launch_bounds__(256) void gray_area_int_kernel(const float* __restrict__ frames, uint8_t* __restrict__ out,
-                                                             int n, int sh, int sw, int dh, int dw, int body)
+                                                             int n, int sh, int sw, int dh, int dw, int body,
+                                                             float* __restrict__ row_max)
 {
+    __shared__ float s_max[4];
+    __shared__ int s_nan[4];
     const int y = blockIdx.x % dh, f = blockIdx.x / dh;
     const float* rowbase = frames + ((size_t)f * sh + (size_t)y * K) * sw * 3;
     uint8_t* D = out + ((size_t)f * dh + y) * dw;
+    float vmax = -INFINITY;
+    int has_nan = 0;
 #pragma unroll 4
     for (int x = threadIdx.x; x < dw; x += 256) {
         int sum = 0;
@@ -52,13 +62,90 @@ __global__ __launch_bounds__(256) void gray_area_int_kernel(const float* __restr
             float row[K * 3];
             __builtin_memcpy(row, base + (size_t)j * sw * 3, sizeof(row));
 #pragma unroll
-            for (int i = 0; i < K; i++) sum += gray_u8(row[i * 3], row[i * 3 + 1], row[i * 3 + 2], (x * K + i) < body);
+            for (int i = 0; i < K; i++) {
+                sum += gray_u8(row[i * 3], row[i * 3 + 1], row[i * 3 + 2], (x * K + i) < body);
+                if (RANGE) {
+                    const float m3 = __builtin_fmaxf(__builtin_fmaxf(row[i * 3], row[i * 3 + 1]), row[i * 3 + 2]);
+                    vmax = __builtin_fmaxf(vmax, m3);
+                    // a + b + c is NaN iff one of them is (or inf - inf, which a frame does not sensibly hold)
+                    const float probe = row[i * 3] + row[i * 3 + 1] + row[i * 3 + 2];
+                    has_nan |= (probe != probe) ? 1 : 0;
+                }
+            }
         }
         int o;
         if (K == 1) o = sum;
         else if (K == 2) o = (sum + 2) >> 2;
         else o = sat_u8_round(sum * (1.f / (K * K)));
         D[x] = (uint8_t)o;
+    }
+    if (RANGE) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            vmax = __builtin_fmaxf(vmax, __shfl_down(vmax, off));
+            has_nan |= __shfl_down(has_nan, off);
+        }
+        if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = vmax; s_nan[threadIdx.x >> 6] = has_nan; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
+            const int nn = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+            row_max[(size_t)f * dh + y] = nn ? NAN : m;
+        }
+    }
+}
+
+// per-frame maximum of the per-row maxima (NaN wins, as in numpy): one workgroup per frame
+__global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict__ row_max, float* __restrict__ frame_max, int rows)
+{
+    __shared__ float s_max[4];
+    __shared__ int s_nan[4];
+    const float* R = row_max + (size_t)blockIdx.x * rows;
+    float vmax = -INFINITY;
+    int has_nan = 0;
+    for (int k = threadIdx.x; k < rows; k += 256) {
+        const float v = R[k];
+        has_nan |= (v != v) ? 1 : 0;
+        vmax = __builtin_fmaxf(vmax, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmax = __builtin_fmaxf(vmax, __shfl_down(vmax, off));
+        has_nan |= __shfl_down(has_nan, off);
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = vmax; s_nan[threadIdx.x >> 6] = has_nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
+        frame_max[blockIdx.x] = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
+    }
+}
+
+// per-row maximum of a clip without producing gray (Motion Apply has no estimation pass): one workgroup per source row
+__global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ frames, float* __restrict__ row_max, int row_floats)
+{
+    __shared__ float s_max[4];
+    __shared__ int s_nan[4];
+    const float4* R = reinterpret_cast<const float4*>(frames + (size_t)blockIdx.x * row_floats);
+    float vmax = -INFINITY;
+    int has_nan = 0;
+    const int nvec = row_floats / 4;   // rows are 16-B aligned whenever row_floats % 4 == 0 (checked by the host)
+    for (int k = threadIdx.x; k < nvec; k += 256) {
+        const float4 v = R[k];
+        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
+        const float probe = (v.x + v.y) + (v.z + v.w);
+        has_nan |= (probe != probe) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmax = __builtin_fmaxf(vmax, __shfl_down(vmax, off));
+        has_nan |= __shfl_down(has_nan, off);
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = vmax; s_nan[threadIdx.x >> 6] = has_nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
+        row_max[blockIdx.x] = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
     }
 }
 
@@ -151,67 +238,132 @@ unsigned grid_for(long long items)
 
 }  // namespace
 
-extern "C" int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w, int work_h,
-                                    int work_w, uint8_t* gray)
+static int gray_run(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w, int work_h, int work_w, uint8_t* gray,
+                    float* frame_max)
 {
-    VSTAB_REQUIRE(ctx != nullptr, "vstab_gray_downscale: ctx is NULL");
-    VSTAB_REQUIRE(frames && gray, "vstab_gray_downscale: NULL pointer argument");
-    VSTAB_REQUIRE(n > 0 && src_h > 0 && src_w > 0 && work_h > 0 && work_w > 0, "vstab_gray_downscale: non-positive size");
-    VSTAB_REQUIRE(work_h <= src_h && work_w <= src_w, "vstab_gray_downscale: working size %dx%d larger than source %dx%d", work_w, work_h, src_w, src_h);
     VSTAB_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int body = src_w & ~7;
     KernelTimer timer(ctx, "gray");
+    float* row_max = nullptr;
+    int range_rows = 0;   // rows of row_max per frame once the gray pass has filled it
 
-    if (work_h == src_h && work_w == src_w) {
-        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
-        VSTAB_HIP(hipGetLastError());
-        return 0;
-    }
+#define LAUNCH_GRAY(K, ROWS, OUT)                                                                                         \
+    do {                                                                                                                  \
+        if (row_max)                                                                                                      \
+            hipLaunchKernelGGL((gray_area_int_kernel<K, true>), dim3((unsigned)(n * (ROWS))), dim3(256), 0, st, frames, OUT, n, src_h, \
+                               src_w, (ROWS), src_w / K, body, row_max);                                                  \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gray_area_int_kernel<K, false>), dim3((unsigned)(n * (ROWS))), dim3(256), 0, st, frames, OUT, n, src_h, \
+                               src_w, (ROWS), src_w / K, body, row_max);                                                  \
+        VSTAB_HIP(hipGetLastError());                                                                                     \
+    } while (0)
+
     // cv::resize: scale = 1/(dsize/ssize); integer-ratio fast path when both are integers within DBL_EPSILON
     const double scale_x = 1. / ((double)work_w / src_w), scale_y = 1. / ((double)work_h / src_h);
     const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
-    const bool fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
-    if (fast && isx == isy && (isx == 2 || isx == 4)) {
-        if (isx == 2)
-            hipLaunchKernelGGL((gray_area_int_kernel<2>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
-        else
-            hipLaunchKernelGGL((gray_area_int_kernel<4>), dim3((unsigned)(n * work_h)), dim3(256), 0, st, frames, gray, n, src_h, src_w, work_h, work_w, body);
-        VSTAB_HIP(hipGetLastError());
-        return 0;
+    const bool same = (work_h == src_h && work_w == src_w);
+    const bool fast = !same && std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
+    const bool fused = fast && isx == isy && (isx == 2 || isx == 4);
+    const int K = same ? 1 : (fused ? isx : 1);
+    if (frame_max) {
+        // the gray pass covers every source sample exactly when its K x K boxes tile the source
+        const int rows = (same || !fused) ? src_h : work_h;
+        if (ctx->d_range.reserve(sizeof(float) * (size_t)n * rows)) return 1;
+        row_max = static_cast<float*>(ctx->d_range.ptr);
+        range_rows = rows;
     }
-    // two passes: full-resolution gray into scratch, then the area resize
-    const size_t full = (size_t)n * src_h * src_w;
-    if (ctx->d_gray_tmp.reserve(full)) return 1;
-    uint8_t* tmp = static_cast<uint8_t*>(ctx->d_gray_tmp.ptr);
-    {
-        hipLaunchKernelGGL((gray_area_int_kernel<1>), dim3((unsigned)(n * src_h)), dim3(256), 0, st, frames, tmp, n, src_h, src_w, src_h, src_w, body);
+    if (same) {
+        LAUNCH_GRAY(1, work_h, gray);
+    } else if (fused) {
+        VSTAB_REQUIRE(work_w * K == src_w && work_h * K == src_h, "vstab_gray_downscale: %dx%d is not %d x %dx%d", src_w, src_h, K, work_w, work_h);
+        if (K == 2) LAUNCH_GRAY(2, work_h, gray);
+        else LAUNCH_GRAY(4, work_h, gray);
+    } else {
+        // two passes: full-resolution gray into scratch, then the area resize
+        const size_t full = (size_t)n * src_h * src_w;
+        if (ctx->d_gray_tmp.reserve(full)) return 1;
+        uint8_t* tmp = static_cast<uint8_t*>(ctx->d_gray_tmp.ptr);
+        LAUNCH_GRAY(1, src_h, tmp);
+        const long long out_items = (long long)n * work_h * work_w;
+        if (fast) {
+            hipLaunchKernelGGL(area_int_u8_kernel, dim3(grid_for(out_items)), dim3(256), 0, st, tmp, gray, n, src_h, src_w, work_h, work_w, isx, isy);
+            VSTAB_HIP(hipGetLastError());
+        } else {
+            std::vector<AreaTabEntry> xtab, ytab;
+            std::vector<int> xstart, ystart;
+            build_area_tab(src_w, work_w, scale_x, xtab, xstart);
+            build_area_tab(src_h, work_h, scale_y, ytab, ystart);
+            // pack the four tables into one staged upload
+            const size_t b_xt = xtab.size() * sizeof(AreaTabEntry), b_yt = ytab.size() * sizeof(AreaTabEntry);
+            const size_t b_xs = xstart.size() * sizeof(int), b_ys = ystart.size() * sizeof(int);
+            std::vector<unsigned char> blob(b_xt + b_yt + b_xs + b_ys);
+            memcpy(blob.data(), xtab.data(), b_xt);
+            memcpy(blob.data() + b_xt, ytab.data(), b_yt);
+            memcpy(blob.data() + b_xt + b_yt, xstart.data(), b_xs);
+            memcpy(blob.data() + b_xt + b_yt + b_xs, ystart.data(), b_ys);
+            void* d_blob = nullptr;
+            if (vstab_stage_params(ctx, blob.data(), blob.size(), &d_blob)) return 1;
+            unsigned char* db = static_cast<unsigned char*>(d_blob);
+            hipLaunchKernelGGL(area_general_u8_kernel, dim3(grid_for(out_items)), dim3(256), 0, st, tmp, gray, n, src_h, src_w, work_h, work_w,
+                               reinterpret_cast<const AreaTabEntry*>(db), reinterpret_cast<const int*>(db + b_xt + b_yt),
+                               reinterpret_cast<const AreaTabEntry*>(db + b_xt), reinterpret_cast<const int*>(db + b_xt + b_yt + b_xs));
+            VSTAB_HIP(hipGetLastError());
+        }
+    }
+#undef LAUNCH_GRAY
+    if (frame_max) {
+        hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, range_rows);
         VSTAB_HIP(hipGetLastError());
     }
-    const long long out_items = (long long)n * work_h * work_w;
-    if (fast) {
-        hipLaunchKernelGGL(area_int_u8_kernel, dim3(grid_for(out_items)), dim3(256), 0, st, tmp, gray, n, src_h, src_w, work_h, work_w, isx, isy);
-        VSTAB_HIP(hipGetLastError());
-        return 0;
-    }
-    std::vector<AreaTabEntry> xtab, ytab;
-    std::vector<int> xstart, ystart;
-    build_area_tab(src_w, work_w, scale_x, xtab, xstart);
-    build_area_tab(src_h, work_h, scale_y, ytab, ystart);
-    // pack the four tables into one staged upload
-    const size_t b_xt = xtab.size() * sizeof(AreaTabEntry), b_yt = ytab.size() * sizeof(AreaTabEntry);
-    const size_t b_xs = xstart.size() * sizeof(int), b_ys = ystart.size() * sizeof(int);
-    std::vector<unsigned char> blob(b_xt + b_yt + b_xs + b_ys);
-    memcpy(blob.data(), xtab.data(), b_xt);
-    memcpy(blob.data() + b_xt, ytab.data(), b_yt);
-    memcpy(blob.data() + b_xt + b_yt, xstart.data(), b_xs);
-    memcpy(blob.data() + b_xt + b_yt + b_xs, ystart.data(), b_ys);
-    void* d_blob = nullptr;
-    if (vstab_stage_params(ctx, blob.data(), blob.size(), &d_blob)) return 1;
-    unsigned char* db = static_cast<unsigned char*>(d_blob);
-    hipLaunchKernelGGL(area_general_u8_kernel, dim3(grid_for(out_items)), dim3(256), 0, st, tmp, gray, n, src_h, src_w, work_h, work_w,
-                       reinterpret_cast<const AreaTabEntry*>(db), reinterpret_cast<const int*>(db + b_xt + b_yt),
-                       reinterpret_cast<const AreaTabEntry*>(db + b_xt), reinterpret_cast<const int*>(db + b_xt + b_yt + b_xs));
+    return 0;
+}
+
+static int gray_check(const char* who, vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w, int work_h, int work_w,
+                      const uint8_t* gray)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
+    VSTAB_REQUIRE(frames && gray, "%s: NULL pointer argument", who);
+    VSTAB_REQUIRE(n > 0 && src_h > 0 && src_w > 0 && work_h > 0 && work_w > 0, "%s: non-positive size", who);
+    VSTAB_REQUIRE(work_h <= src_h && work_w <= src_w, "%s: working size %dx%d larger than source %dx%d", who, work_w, work_h, src_w, src_h);
+    return 0;
+}
+
+extern "C" int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w, int work_h,
+                                    int work_w, uint8_t* gray)
+{
+    if (int rc = gray_check("vstab_gray_downscale", ctx, frames, n, src_h, src_w, work_h, work_w, gray)) return rc;
+    return gray_run(ctx, frames, n, src_h, src_w, work_h, work_w, gray, nullptr);
+}
+
+extern "C" int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w, int work_h,
+                                          int work_w, uint8_t* gray, float* frame_max)
+{
+    if (int rc = gray_check("vstab_gray_downscale_range", ctx, frames, n, src_h, src_w, work_h, work_w, gray)) return rc;
+    VSTAB_REQUIRE(frame_max != nullptr, "vstab_gray_downscale_range: frame_max is NULL");
+    return gray_run(ctx, frames, n, src_h, src_w, work_h, work_w, gray, frame_max);
+}
+
+extern "C" int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, float* frame_max)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_frame_range: ctx is NULL");
+    VSTAB_REQUIRE(frames && frame_max, "vstab_frame_range: NULL pointer argument");
+    VSTAB_REQUIRE(n > 0 && h > 0 && w > 0, "vstab_frame_range: non-positive size");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // a frame is h*w*3 contiguous floats: cut it into pieces of a multiple of 4 floats that divides it evenly
+    const long long per_frame = (long long)h * w * 3;
+    long long piece = 0;
+    for (long long cand : {(long long)w * 3, (long long)w * 3 * 2, (long long)w * 3 * 4, per_frame})
+        if (cand % 4 == 0 && per_frame % cand == 0 && (reinterpret_cast<uintptr_t>(frames) % 16) == 0) { piece = cand; break; }
+    VSTAB_REQUIRE(piece > 0, "vstab_frame_range: frames of %dx%d cannot be cut into 16-byte aligned pieces", w, h);
+    const long long pieces = per_frame / piece;
+    VSTAB_REQUIRE((long long)n * pieces < 0x7fffffffLL && piece < 0x7fffffffLL, "vstab_frame_range: clip too large");
+    if (ctx->d_range.reserve(sizeof(float) * (size_t)n * pieces)) return 1;
+    float* row_max = static_cast<float*>(ctx->d_range.ptr);
+    KernelTimer timer(ctx, "range");
+    hipLaunchKernelGGL(row_max_kernel, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
+    hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }

@@ -57,7 +57,7 @@ struct vstab_ctx {
     ScratchBuf h_params, d_params;
     hipEvent_t ev_params_free = nullptr;  // recorded after the H2D copy of h_params
     // DIS / fit workspaces (grow-only)
-    ScratchBuf d_dis, d_fit, h_fit, d_gray_tmp;
+    ScratchBuf d_dis, d_fit, h_fit, d_gray_tmp, d_range;
     // Device-side failure reports: one host-resident word (coherent, device-mapped).  A kernel ORs a VSTAB_STATUS_*
     // bit into it through d_status; the host reads h_status after any stream synchronisation at no cost.
     volatile int* h_status = nullptr;

@@ -146,17 +146,27 @@ def select_transitions(fit_records, requested_mode: str):
     return mats, modes, confs.tolist(), resids.tolist(), _MODE_NAME[active]
 
 
-def estimate_transitions(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
-    """F2-F5 for frames [N,H,W,3] on the device -> per-pair candidate fits (structured table [N-1,3])."""
-    gray = ctx.gray_downscale(device_frames, working_size)
+def _gray(ctx, device_frames, working_size, peaks_out):
+    """F2, plus the per-frame maxima of the same pass when the caller still owes the value-range sniff (F0)."""
+    if peaks_out is None:
+        return ctx.gray_downscale(device_frames, working_size)
+    gray, peaks = ctx.gray_downscale(device_frames, working_size, want_range=True)
+    peaks_out.append(peaks)
+    return gray
+
+
+def estimate_transitions(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True, peaks_out=None):
+    """F2-F5 for frames [N,H,W,3] on the device -> per-pair candidate fits (structured table [N-1,3]).
+    peaks_out: a list that receives the device tensor of per-frame maxima (see host_math.resolve_value_range)."""
+    gray = _gray(ctx, device_frames, working_size, peaks_out)
     _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True, clip_start=clip_start)
     return ctx.sample_fit_batch(grid, SAMPLE_STEP, transform_mode)
 
 
-def estimate_transitions_phase(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
+def estimate_transitions_phase(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True, peaks_out=None):
     """Fallback estimator (flow.py:110-130, 325-330): phase correlation of consecutive estimation images.  Every pair
     is reported as a "translation" fit whatever `transform_mode` asks for; confidence = peak response, residual 0."""
-    gray = ctx.gray_downscale(device_frames, working_size)
+    gray = _gray(ctx, device_frames, working_size, peaks_out)
     table, _ = ctx.phase_correlate_batch(gray)
     return table
 
@@ -169,10 +179,10 @@ CLASSIC_GFTT = dict(max_corners=400, quality=0.01, min_distance=7.0, block_size=
 CLASSIC_LK = dict(win=31, max_level=3, max_count=50, epsilon=0.01)
 
 
-def estimate_transitions_classic(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True):
+def estimate_transitions_classic(ctx, device_frames, working_size, transform_mode: str, clip_start: bool = True, peaks_out=None):
     """Classic estimator (classic.py:69-160) for frames [N,H,W,3] on the device -> candidate fits [N-1,3]:
     corners of frame i (HIP) -> pyramidal LK into frame i+1 (HIP) -> model fits on the tracked pairs (HIP)."""
-    gray = ctx.gray_downscale(device_frames, working_size)
+    gray = _gray(ctx, device_frames, working_size, peaks_out)
     corners, counts = ctx.gftt_batch(gray[:-1], **CLASSIC_GFTT)
     pairs = ctx.lk_track_batch(gray, corners, counts, **CLASSIC_LK)
     return ctx.points_fit_batch(pairs, counts, transform_mode)
@@ -194,6 +204,7 @@ def _fps_fields(context: hm.VideoContext, frame_rate) -> Tuple[float, Optional[f
 
 def _host_frames(context: hm.VideoContext) -> np.ndarray:
     if context.batch is not None:
+        hm.resolve_value_range(context)
         return context.batch.detach().cpu().numpy()
     return np.stack([hm._ensure_rgb(f) for f in context.frames], axis=0)
 
@@ -509,7 +520,15 @@ def _stabilize_frames(
 
     # ---- estimation (F2-F5) -------------------------------------------------
     estimate = _ESTIMATORS[estimator]
-    fit_records = estimate(ctx, device_frames, working_size, transform_mode)
+    peaks = [] if context.range_pending else None
+    fit_records = estimate(ctx, device_frames, working_size, transform_mode, peaks_out=peaks)
+    if peaks and hm.resolve_value_range(context, peaks[0]):
+        # F0 (stabilizer_utils.py:127-131): some frame turned out to be 0..255 float data.  The estimation above ran
+        # optimistically on the tensor as given (the gray pass reported the per-frame maxima for free); the frames
+        # have been rescaled now, so it is repeated on the rescaled clip.  0..1 input -- the ComfyUI IMAGE contract --
+        # never takes this branch.
+        device_frames = context.device_batch(ctx)
+        fit_records = estimate(ctx, device_frames, working_size, transform_mode)
     progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
     check_interrupt()
 

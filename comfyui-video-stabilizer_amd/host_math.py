@@ -49,6 +49,10 @@ class VideoContext:
     template_kind: str
     template_meta: Dict[str, Any]
     batch: Any = field(default=None, repr=False)  # torch.Tensor [N,H,W,3] f32 0..1 if already assembled
+    # True while the per-frame value-range sniff of stabilizer_utils.py:127-131 (max > 1.5 -> /255) is still owed for
+    # `batch`: the GPU pipelines get the per-frame maxima from their first pass over the pixels (the gray kernel, or
+    # vstab_frame_range) instead of reading the clip once more on the host, and call resolve_value_range().
+    range_pending: bool = False
 
     def device_batch(self, ctx):
         """[N,H,W,3] f32 tensor on ctx.device (uploaded once, cached)."""
@@ -118,8 +122,9 @@ def _to_numpy_frame(frame: Any) -> Tuple[np.ndarray, FrameAdapter]:
 
 
 def _fast_batch(value: Any):
-    """The ComfyUI IMAGE case: a float32 [N,H,W,3] tensor. Range sniffing (>1.5 -> /255, per frame,
-    stabilizer_utils.py:127-131) is done with tensor ops on whatever device the tensor lives on."""
+    """The ComfyUI IMAGE case: a float32 [N,H,W,3] tensor, kept as one batch.  The per-frame range sniff (>1.5 -> /255,
+    stabilizer_utils.py:127-131) is deferred (VideoContext.range_pending): the first GPU pass over the pixels reports
+    the per-frame maxima, see resolve_value_range()."""
     if torch is None or not isinstance(value, torch.Tensor):
         return None
     if value.ndim != 4 or value.dtype != torch.float32 or value.shape[-1] != 3 or value.shape[0] == 0:
@@ -127,13 +132,37 @@ def _fast_batch(value: Any):
     n, h, w, _ = value.shape
     if h <= 4:  # tiny heights can trip the reference's per-frame channel-first sniff: take the slow path
         return None
-    t = value.detach()
-    peaks = t.reshape(n, -1).amax(dim=1)
-    big = peaks > 1.5
+    return value.detach().contiguous()
+
+
+def apply_value_range(batch, peaks):
+    """stabilizer_utils.py:127-131 on a whole batch: frames whose maximum exceeds 1.5 are divided by 255 (float32).
+    `peaks`: per-frame maxima (tensor on any device; NaN compares False, as `float(arr.max()) > 1.5` does).
+    Returns (batch -- a rescaled copy if anything changed, else the same tensor --, value_range of frame 0)."""
+    big = (peaks > 1.5).to(batch.device)
     if bool(big.any()):
-        t = t.clone()
-        t[big] = t[big] / 255.0
-    return t.contiguous(), ("0_255" if bool(big[0]) else "0_1")
+        batch = batch.clone()
+        batch[big] = batch[big] / 255.0
+    return batch, ("0_255" if bool(big[0]) else "0_1")
+
+
+def resolve_value_range(context: "VideoContext", peaks=None) -> bool:
+    """Settle a pending range sniff of context.batch.  `peaks` = per-frame maxima from a GPU pass, or None to compute
+    them here with tensor ops (host paths that never reach a kernel: single-frame passthrough, crop bypass on CPU).
+    Returns True if frames were rescaled, i.e. whatever was derived from the unscaled pixels must be recomputed."""
+    if not context.range_pending:
+        return False
+    if peaks is None:
+        peaks = context.batch.reshape(context.batch.shape[0], -1).amax(dim=1)
+    new_batch, vrange = apply_value_range(context.batch, peaks)
+    changed = new_batch is not context.batch
+    context.batch = new_batch
+    context.adapter.value_range = vrange
+    context.range_pending = False
+    if changed and context.frames and context.frames[0] is not None:
+        host = new_batch if new_batch.device.type == "cpu" else None
+        context.frames[:] = [host[i].numpy() if host is not None else None for i in range(len(context.frames))]
+    return changed
 
 
 def _normalize_video_input(value: Any) -> VideoContext:
@@ -152,14 +181,13 @@ def _normalize_video_input(value: Any) -> VideoContext:
     else:
         seq, kind, tmeta, fps = value, "sequence", {}, None
 
-    fast = _fast_batch(seq)
-    if fast is not None:
-        batch, vrange = fast
+    batch = _fast_batch(seq)
+    if batch is not None:
         n, h, w, _ = batch.shape
         host = batch if batch.device.type == "cpu" else None
         views = [host[i].numpy() if host is not None else None for i in range(n)]
-        adapter = FrameAdapter(np.dtype(np.float32), False, vrange, "torch", False)
-        return VideoContext(views, adapter, int(w), int(h), 3, fps, kind, tmeta, batch=batch)
+        adapter = FrameAdapter(np.dtype(np.float32), False, "0_1", "torch", False)
+        return VideoContext(views, adapter, int(w), int(h), 3, fps, kind, tmeta, batch=batch, range_pending=True)
 
     frames: List[np.ndarray] = []
     first: Optional[FrameAdapter] = None

@@ -122,6 +122,9 @@ _SIGNATURES = {
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_gray_downscale": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_gray_downscale_range": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vstab_frame_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vstab_dis_flow_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_dis_set_clip_start": (C.c_int, [C.c_void_p, C.c_int]),
@@ -329,8 +332,9 @@ class Context:
         return dst, mask
 
     # ------------------------------------------------------------------ estimation
-    def gray_downscale(self, frames, work_size):
-        """frames [N,H,W,3] f32 -> gray u8 [N,work_h,work_w] (work_size=(w,h) or None for full size)."""
+    def gray_downscale(self, frames, work_size, want_range=False):
+        """frames [N,H,W,3] f32 -> gray u8 [N,work_h,work_w] (work_size=(w,h) or None for full size).
+        want_range: also the per-frame maximum sample (device f32 [N], NaN-propagating) from the same pass."""
         torch = self.torch
         src = self._as_device_frames(frames)
         n, sh, sw, ch = src.shape
@@ -339,9 +343,24 @@ class Context:
         ww, wh = (sw, sh) if work_size is None else (int(work_size[0]), int(work_size[1]))
         gray = torch.empty((n, wh, ww), dtype=torch.uint8, device=self.device)
         self.use_torch_stream()
+        if want_range:
+            peaks = torch.empty((n,), dtype=torch.float32, device=self.device)
+            _check(self.lib.vstab_gray_downscale_range(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray), _dev_ptr(peaks)),
+                   "vstab_gray_downscale_range")
+            return gray, peaks
         _check(self.lib.vstab_gray_downscale(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray)),
                "vstab_gray_downscale")
         return gray
+
+    def frame_range(self, frames):
+        """Per-frame maximum sample of frames [N,H,W,3] f32 on the device (NaN-propagating) -> device f32 [N]."""
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        peaks = torch.empty((n,), dtype=torch.float32, device=self.device)
+        self.use_torch_stream()
+        _check(self.lib.vstab_frame_range(self.handle, _dev_ptr(src), n, sh, sw * ch // 3, _dev_ptr(peaks)), "vstab_frame_range")
+        return peaks
 
     def dis_flow_batch(self, gray, sample_step=8, want_full=False, want_grid=True, clip_start=True):
         """gray u8 [N,h,w] (device) -> (flow [N-1,h,w,2] | None, grid_flow [N-1,gh,gw,2] | None).

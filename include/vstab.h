@@ -127,6 +127,17 @@ int vstab_blur_sample_matrices(const double* matrices, int total, int first, int
 int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w,
                          int work_h, int work_w, uint8_t* gray);
 
+/* ---- F0 + F2: the same pass with the value-range sniff of the input adaptation folded in ------
+ * nodes/stabilizer_utils.py:127-131 decides PER FRAME whether float input is 0..255 (`float(arr.max()) > 1.5` -> /255):
+ * one more full read of every frame.  The gray pass reads every sample anyway, so it can report the per-frame maximum
+ * (NaN if the frame holds one, as numpy's max) in the same 24.9 MB read: frame_max dev [n] f32.  The caller runs the
+ * estimation optimistically on the tensor as given and, in the rare case that a maximum exceeds 1.5, rescales those
+ * frames and repeats it (host_math.resolve_value_range).
+ * vstab_frame_range: the sniff alone (Motion Apply has no estimation pass), an HBM-bound read of the clip. */
+int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w,
+                               int work_h, int work_w, uint8_t* gray, float* frame_max);
+int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, float* frame_max);
+
 /* ---- F3 (+F4): DIS dense optical flow over consecutive pairs ---------------
  * Replaces cv2.DISOpticalFlow (PRESET_MEDIUM, finestScale 2, patchSize 8,
  * patchStride 4, spatial propagation) created at nodes/video_stabilizer_flow.py:82-86

@@ -54,3 +54,38 @@ def test_4k_sizes(ctx, oracle):
     eye = np.tile(np.eye(3, dtype=np.float32), (2, 1, 1))
     dst, mask, cnt = ctx.warp_batch(frames, eye, (3840, 2160), border=(0.5, 0.5, 0.5), want_count=True)
     assert torch.equal(dst.cpu(), frames) and int(cnt.sum()) == 0
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_range_sniff_from_the_gray_pass(ctx, case):
+    """F0's per-frame `float(arr.max()) > 1.5` (stabilizer_utils.py:127-131) comes out of the gray pass: the per-frame
+    maxima equal numpy's, exactly, for every resize path (fused 1x/2x/4x boxes, two-pass general ratios), and the gray
+    image is the one the plain entry point produces.  NaN propagates as in numpy (the comparison is then False)."""
+    n, h, w, work = case
+    rng = np.random.default_rng(h * 7 + w)
+    frames = synth_frames(n, h, w, seed=h)
+    frames[0] *= 255.0                                   # a 0..255 float frame
+    frames[0, h - 1, w - 1, 2] = 300.5                   # the maximum sits in the last sample of the frame
+    if n > 1:
+        frames[1, rng.integers(h), rng.integers(w), rng.integers(3)] = np.nan
+    gray, peaks = ctx.gray_downscale(frames, work, want_range=True)
+    assert np.array_equal(gray.cpu().numpy(), ctx.gray_downscale(frames, work).cpu().numpy())
+    got = peaks.cpu().numpy()
+    want = frames.reshape(n, -1).max(axis=1)
+    assert got.dtype == np.float32 and np.array_equal(got, want, equal_nan=True)
+    assert got[0] == np.float32(300.5) and (n == 1 or np.isnan(got[1]))
+    alone = ctx.frame_range(frames).cpu().numpy()
+    assert np.array_equal(alone, want, equal_nan=True)
+
+
+def test_frame_range_at_full_size(ctx):
+    import torch
+
+    g = torch.Generator().manual_seed(9)
+    frames = torch.rand((3, 1080, 1920, 3), generator=g, dtype=torch.float32)
+    frames[2, 1079, 1919, 1] = 1.75
+    want = frames.reshape(3, -1).amax(dim=1)
+    dev = frames.cuda()
+    assert torch.equal(ctx.frame_range(dev).cpu(), want)
+    _, peaks = ctx.gray_downscale(dev, (960, 540), want_range=True)
+    assert torch.equal(peaks.cpu(), want)

@@ -195,7 +195,14 @@ def test_normalize_video_input_layouts(hm):
     t[1] *= 255.0
     c = hm._normalize_video_input(t)
     ref = hm._normalize_video_input([f for f in t.numpy()])
-    assert c.batch is not None and np.array_equal(c.batch.numpy(), np.stack(ref.frames))
+    # the sniff is owed until a pass over the pixels has seen the per-frame maxima (the GPU pipelines take them from the
+    # gray kernel; here the host form of the same rule settles it)
+    assert c.batch is not None and c.range_pending and c.batch.data_ptr() == t.data_ptr()
+    assert hm.resolve_value_range(c) and not c.range_pending and c.adapter.value_range == "0_1"
+    assert np.array_equal(c.batch.numpy(), np.stack(ref.frames)) and np.array_equal(np.stack(c.frames), np.stack(ref.frames))
+    assert t[1].max() > 1.5, "the caller's tensor is never modified"
+    plain = hm._normalize_video_input(torch.from_numpy(np.tile(batch, (1, 2, 2, 1)).copy()))
+    assert not hm.resolve_value_range(plain) and plain.batch is not None
     for name, err in GOLD["normalize_errors"].items():
         with pytest.raises(ValueError) as info:
             hm._normalize_video_input([] if name == "empty" else {"x": 1})

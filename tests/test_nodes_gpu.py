@@ -304,3 +304,39 @@ def test_pinned_output_option_is_transparent(api, ctx, monkeypatch):
     pinned = api.nodes.VideoStabilizerFlow.execute(*args)
     assert pinned[0].device.type == "cpu" and pinned[0].is_pinned() and pinned[1].is_pinned() and not plain[0].is_pinned()
     assert torch.equal(plain[0], pinned[0]) and torch.equal(plain[1], pinned[1]) and plain[2] == pinned[2]
+
+
+def test_value_range_sniff_is_settled_on_the_gpu(api, ctx):
+    """F0 (stabilizer_utils.py:127-131): float frames whose maximum exceeds 1.5 are 0..255 data and get divided by 255,
+    decided per frame.  The nodes take the per-frame maxima from their first pass over the pixels on the GPU (gray
+    kernel / vstab_frame_range) and repeat the estimation on the rescaled clip when needed: a clip with two 0..255
+    frames must give exactly the result of the same clip rescaled by the caller, and the caller's tensor stays untouched."""
+    import torch
+
+    from tests.test_dis_gpu import moving_clip
+
+    gray, _ = moving_clip(6, 136, 240, seed=77)
+    clean = np.ascontiguousarray(np.repeat(gray[..., None].astype(np.float32) / 255.0, 3, axis=-1))
+    mixed = clean.copy()
+    mixed[1] = mixed[1] * 255.0
+    mixed[4] = mixed[4] * 255.0
+    # the reference divides float32 by 255.0: the rescaled frames are (x*255)/255, not bit-equal to x
+    expect_in = clean.copy()
+    expect_in[1] = mixed[1] / np.float32(255.0)
+    expect_in[4] = mixed[4] / np.float32(255.0)
+    args = (16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    for device in ("cpu", "cuda"):
+        t = torch.from_numpy(mixed.copy()).to(device)
+        keep = t.clone()
+        got = api.nodes.VideoStabilizerFlow.execute(t, *args)
+        want = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(expect_in).to(device), *args)
+        assert torch.equal(t, keep), "inputs are read-only views (SURVEY 8b: ownership)"
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and got[2] == want[2]
+    blockmeta = got[2]
+    t = torch.from_numpy(mixed.copy())
+    a = api.nodes.VideoStabilizerMotionApply.execute(t, blockmeta, "expand", "bicubic", "#102030", 0.5, "Draft")
+    b = api.nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(expect_in), blockmeta, "expand", "bicubic", "#102030", 0.5, "Draft")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    # single-frame passthrough settles the sniff on the host
+    one = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(mixed[1:2].copy()), *args)
+    assert np.array_equal(one[0].numpy(), expect_in[1:2])
