@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: stabilized frames/s of the Video Stabilizer Flow hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 256 synthetic 1080p frames per GPU, Flow node defaults
-(DIS flow -> similarity fit -> box-smoothed trajectory, strength 0.7 / smooth 0.5 / 16 fps ->
-crop_and_pad warp with padding mask).  One "step" = one full pass of the hot path over the clip
-with the input frames already resident in HBM and the outputs left in HBM:
-    gray+downscale -> DIS (255 pairs) -> fit -> [all-gather of fit records if N > 1] ->
-    trajectory -> framing -> warp + mask + padding counts.
-N > 1: one process per GPU (torchrun), the clip is 256*N frames sharded contiguously with a
-1-frame halo; weak scaling (per-GPU work fixed).  value = frames of all ranks / max-over-ranks time.
+    python bench.py --gpus N --steps K --warmup W
 
-Also on the JSON line:
-  roofline     - the warp kernel (dominant HBM stream): algorithmic 28 B per output pixel x pixels
-                 per launch / average launch time from HIP events on the launch stream
-  cpu_baseline - the CPU oracle (a C restatement of the reference's OpenCV path; "port") timed on
-                 this host's cores over a bounded sample of the same clip (rank 0, N=1 only)
+One "step" = one full pass of the hot path over the clip with the input frames already resident in HBM and the
+outputs left in HBM, entered at the node boundary (`_normalize_video_input` on the resident tensor):
+    F0 input adaptation (the value-range sniff rides on the gray pass) -> gray+downscale -> DIS (all pairs) -> fit ->
+    [all-gather of fit records if N > 1] -> trajectory -> framing -> warp + mask + padding counts -> meta.
+
+Workloads (BASELINE.json configs):
+  N = 1  C2: 256 synthetic 1080p frames, Flow similarity + crop_and_pad, defaults.
+  N > 1  C4: ONE 1024-frame 1080p clip sharded contiguously over the N ranks (1-frame halo, RCCL all-gather of the
+         fit records): total work fixed -> "scaling": "strong".  `--total-frames T` picks another clip length (also at
+         N = 1: `--gpus 1 --total-frames 1024` is the same clip on one GPU), `--frames F` fixes the frames per GPU
+         instead ("weak").
+N > 1 needs one process per GPU.  Started under torchrun (WORLD_SIZE set) this file is a rank; started plainly with
+--gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before
+anything touches the GPU and relays its output (never an exec).
+
+Also on the JSON line (rank 0):
+  roofline       the warp kernel (dominant HBM stream): algorithmic 28 B per output pixel x pixels per launch /
+                 average launch time from HIP events on the launch stream
+  cpu_baseline   the CPU oracle (a C restatement of the reference's OpenCV path; "port") timed on this host's cores
+                 over a bounded sample of the same clip (N = 1 only)
+  host_roundtrip the node as ComfyUI calls it: CPU tensor in -> CPU tensors out (PCIe-inclusive; never `value`)
+  motion_apply   Motion Apply rates for C3 (1080p, bicubic, blur 0.5, S=17) and C5's per-GPU share (4K, bilinear,
+                 blur 0.5, S=33), device-resident (N = 1 only; measured outside the timed loop)
+  config.rank0_host_ms   (N > 1) host wall-clock per phase of rank 0's step: the gathers and plan+meta are the
+                 replicated/serial part that bounds strong scaling
 """
 
 from __future__ import annotations
@@ -22,6 +35,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,6 +47,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 WARP_BYTES_PER_PIXEL = 28  # read 12 B source + write 12 B frame + 4 B mask
+FLOW_ARGS = ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
 
 
 def camera_matrices(n: int, offset: int, width: int, height: int) -> np.ndarray:
@@ -96,6 +111,8 @@ def cpu_baseline(frames_host: np.ndarray, threads: int) -> dict:
     n, h, w, _ = frames_host.shape
     size = (w, h)
     t0 = time.perf_counter()
+    peaks = vo.frame_max(frames_host)            # F0: the per-frame range sniff of stabilizer_utils.py:127-131
+    assert not (peaks > 1.5).any()
     work = hm._working_estimation_size(w, h)
     gray = vo.gray_for_estimation(frames_host, work)
     flow = vo.dis_flow_clip(gray)
@@ -116,31 +133,113 @@ def cpu_baseline(frames_host: np.ndarray, threads: int) -> dict:
     vo.warp_clip(frames_host, final, size, border=hm.border_value((127, 127, 127)))
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same synthetic {w}x{h} clip, full path (gray, DIS, fit, trajectory, warp+mask), "
-                      f"OpenMP over frames, {dt:.1f} s"}
+            "sample": f"{n} frames of the same synthetic {w}x{h} clip, full path (range sniff, gray, DIS, fit, trajectory, "
+                      f"warp+mask), OpenMP over frames, {dt:.1f} s"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU (BASELINE configs[1]: 256)")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
-    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
-    args = ap.parse_args()
+def launch_children(args, argv) -> int:
+    """--gpus N > 1 without a torchrun environment: run the ranks as children of this (GPU-free) process."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def measure_host_roundtrip(nodes, frames_host, repeats: int = 2) -> dict:
+    """The node exactly as ComfyUI calls it (stabilizer_utils.py:200-221: CPU tensors out)."""
+    import torch
+
+    best = None
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = nodes.VideoStabilizerFlow.execute(frames_host, 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+        dt = time.perf_counter() - t0
+        assert out[0].device.type == "cpu" and out[0].shape[0] == frames_host.shape[0]
+        del out
+        best = dt if best is None else min(best, dt)
+    n = frames_host.shape[0]
+    gb = frames_host.numel() * 4 / 1e9
+    return {"ms": round(best * 1e3, 1), "frames_per_s": round(n / best, 1), "frames": n,
+            "pinned_output": os.environ.get("VSTAB_PINNED_OUTPUT", "0") not in ("", "0", "false", "False"),
+            "bytes_in_GB": round(gb, 2), "bytes_out_GB": round(gb * 4 / 3, 2),
+            "note": "CPU tensor in -> Video Stabilizer Flow node -> CPU tensors out, best of %d" % repeats}
+
+
+def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
+    """Motion Apply rates for BASELINE configs C3 / C5 (per-GPU share), device-resident, HIP-event kernel time and
+    wall time per pass; the motion comes from the reference's shake generator blocks (tests/golden/shake_*.json)."""
+    from vstab_amd import apply_pipeline as ap
+    from vstab_amd import host_math as hm
+
+    out = {}
+    plans = [("c3_1080p_bicubic_blur0.5_S17", "shake_c3_256x1080p.json", 256, 1080, 1920, "crop_and_pad", "bicubic", 17),
+             ("c5_4k_expand_bilinear_blur0.5_S33", "shake_c5_64x4k.json", 64, 2160, 3840, "expand", "bilinear", 33)]
+    for key, fixture, n, h, w, framing, interp, samples in plans:
+        meta = {"motion_meta": json.loads((ROOT / "tests" / "golden" / fixture).read_text())}
+        frames = synth_clip(n, 0, h, w, device)
+        torch.cuda.synchronize()
+
+        def once():
+            c = hm._normalize_video_input(frames)
+            r = ap.apply_motion(c, meta, (127, 127, 127), framing_mode=framing, interpolation=interp, motion_blur=0.5,
+                                motion_blur_samples=samples, ctx=ctx, keep_on_device=True)
+            return r
+
+        r = once()
+        shape = list(r.frames.shape)
+        del r
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = once()
+            del r
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kernel_ms, launches = ctx.kernel_ms_stats("warp_blur")
+        kernel_ms /= max(launches, 1)
+        px = shape[1] * shape[2] * n
+        out[key] = {"frames": n, "out_shape": shape, "ms_per_pass": round(dt * 1e3, 2), "frames_per_s": round(n / dt, 1),
+                    "kernel_ms": round(kernel_ms, 2), "samples_per_s": round(px * samples / (kernel_ms * 1e-3), 0),
+                    "hbm_GBs_algorithmic": round(WARP_BYTES_PER_PIXEL * px / (kernel_ms * 1e-3) / 1e9, 1),
+                    "bound": "valu (not HBM): S x (f64 coordinates + taps) per output pixel"}
+        del frames
+        torch.cuda.empty_cache()
+    return out
+
+
+def main() -> int:
+    ap_ = argparse.ArgumentParser()
+    ap_.add_argument("--gpus", type=int, default=1)
+    ap_.add_argument("--steps", type=int, default=5)
+    ap_.add_argument("--warmup", type=int, default=2)
+    ap_.add_argument("--frames", type=int, default=None, help="frames per GPU (weak scaling); default: C2 = 256 at N=1")
+    ap_.add_argument("--total-frames", type=int, default=None, help="clip length sharded over all GPUs (strong scaling); default at N>1: C4 = 1024")
+    ap_.add_argument("--height", type=int, default=1080)
+    ap_.add_argument("--width", type=int, default=1920)
+    ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
+    ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
+    ap_.add_argument("--no-extras", action="store_true", help="skip host_roundtrip / motion_apply (N=1 extras outside the timed loop)")
+    args = ap_.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_children(args, sys.argv[1:])
 
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -162,26 +261,33 @@ def main() -> None:
     from vstab_amd import distributed as vd
     from vstab_amd import flow_pipeline as fp
     from vstab_amd import host_math as hm
-    from vstab_amd import native
+    from vstab_amd import native, nodes
 
     ctx = native.Context(local_rank)
     ctx.set_timing(True)
 
-    n_local, h, w = args.frames, args.height, args.width
-    total = n_local * world
+    h, w = args.height, args.width
+    if args.frames is not None:
+        total, scaling, label = args.frames * world, "weak", f"{args.frames} frames per GPU"
+    elif args.total_frames is not None:
+        total, scaling, label = args.total_frames, "strong", f"one {args.total_frames}-frame clip"
+    elif world == 1:
+        total, scaling, label = 256, "weak", "C2: 256-frame clip"
+    else:
+        total, scaling, label = 1024, "strong", "C4: one 1024-frame clip"
     start, end = vd.shard_range(total, world, rank)
-    halo = 1 if rank > 0 else 0
+    n_local = end - start
+    halo = 1 if (rank > 0 and n_local > 0) else 0
     frames = synth_clip(n_local + halo, start - halo, h, w, device)
     torch.cuda.synchronize()
+    stats: dict = {}
 
     def step():
         if not use_dist:
-            context = hm.VideoContext([None] * n_local, hm.FrameAdapter(np.dtype(np.float32), False, "0_1", "torch", False),
-                                      w, h, 3, None, "sequence", {}, batch=frames)
-            res = fp._stabilize_frames(context, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
-                                       ctx=ctx, keep_on_device=True)
+            context = hm._normalize_video_input(frames)   # F0 at the node boundary (the range sniff rides on the gray pass)
+            res = fp._stabilize_frames(context, *FLOW_ARGS, ctx=ctx, keep_on_device=True)
             return res.frames, res.masks, res.meta
-        return vd.stabilize_sharded(ctx, frames, total, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+        return vd.stabilize_sharded(ctx, frames, total, *FLOW_ARGS, stats=stats, want_meta=(rank == 0))
 
     def fence():
         if use_dist:
@@ -193,6 +299,7 @@ def main() -> None:
         del out
     fence()
     ctx.set_timing(True)   # clears the per-kind totals: only the timed steps below are counted
+    stats.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -205,6 +312,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    rc = 0
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
@@ -218,12 +326,25 @@ def main() -> None:
         warp_avg_ms = stage_ms["warp"]
         launch_bytes = WARP_BYTES_PER_PIXEL * out_w * out_h * n_local
         achieved = launch_bytes / (warp_avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "warp_traffic.json"
         if tfile.exists():
             tj = json.loads(tfile.read_text())
             if tj.get("frames") == n_local and tj.get("size") == [w, h]:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/warp_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, not collected in this run)"
+        config = {
+            "workload": f"{label}, {w}x{h}, Video Stabilizer Flow (DIS) similarity + crop_and_pad, defaults (strength 0.7, "
+                        "smooth 0.5, 16 fps), device-resident in/out, entered at the node's input adaptation",
+            "frames_per_gpu": n_local,
+            "total_frames": total,
+            "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo, RCCL all-gather of fit records",
+            "stage_ms": {k: round(float(v), 3) for k, v in stage_ms.items()},
+        }
+        if use_dist:
+            config["rank0_host_ms"] = {k: round(v / args.steps, 3) for k, v in stats.items()}
+            config["rank0_host_ms_note"] = ("host wall-clock per phase of rank 0's step; gather_fits + gather_counts = the two "
+                                            "collectives, plan + meta = replicated host work (meta on rank 0 only)")
         line = {
             "metric": "stabilized frames/sec (1080p, similarity mode)",
             "value": round(value, 2),
@@ -233,18 +354,11 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": f"C2: {n_local}-frame {w}x{h} clip per GPU, Video Stabilizer Flow (DIS) similarity + crop_and_pad, "
-                            "defaults (strength 0.7, smooth 0.5, 16 fps), device-resident in/out",
-                "frames_per_gpu": n_local,
-                "total_frames": total,
-                "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo, RCCL all-gather of fit records",
-                "stage_ms": {k: round(float(v), 3) for k, v in stage_ms.items()},
-            },
+            "config": config,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "warp_kernel<bilinear,q5,mask>",
@@ -253,18 +367,32 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "launch_ms": round(warp_avg_ms, 4),
                 "algorithmic_bytes_per_launch": launch_bytes,
             },
         }
-        if world == 1 and args.cpu_frames >= 2:
-            threads = min(16, len(os.sched_getaffinity(0)))
-            sample = frames[: min(args.cpu_frames, n_local)].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample, threads)
+        if world == 1 and not use_dist:
+            if args.cpu_frames >= 2:
+                threads = min(16, len(os.sched_getaffinity(0)))
+                sample = frames[: min(args.cpu_frames, n_local)].cpu().numpy()
+                line["cpu_baseline"] = cpu_baseline(sample, threads)
+                del sample
+            if not args.no_extras:
+                try:
+                    host = frames.cpu()
+                    line["host_roundtrip"] = measure_host_roundtrip(nodes, host)
+                    del host
+                    del frames
+                    torch.cuda.empty_cache()
+                    line["motion_apply"] = measure_motion_apply(ctx, torch, device)
+                except Exception as exc:  # the headline line must survive a failure of the extras
+                    line["extras_error"] = f"{type(exc).__name__}: {exc}"
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -65,6 +65,25 @@ def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=No
     return np.concatenate([host[r, : counts[r]] for r in range(world)], axis=0)
 
 
+def _gather_counts(counts, per_rank: Sequence[int], group=None, on_device: bool = False) -> np.ndarray:
+    """all-gather of the per-frame padded-pixel counts.  With RCCL the int32 device tensor the warp kernel filled goes
+    into the collective as it is, stream-ordered behind the kernel (no host round trip before the exchange) and the
+    gathered table comes back in one D2H copy; with gloo (CPU tests) the counts travel as host rows."""
+    import torch
+    import torch.distributed as dist
+
+    if not on_device:
+        return _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), per_rank, group=group).reshape(-1)
+    world = dist.get_world_size(group)
+    rows = max(max(per_rank), 1)
+    padded = torch.zeros((rows,), dtype=torch.int32, device=counts.device)
+    padded[: counts.shape[0]] = counts
+    flat = torch.empty((world, rows), dtype=torch.int32, device=counts.device)
+    dist.all_gather_into_tensor(flat, padded, group=group)
+    host = flat.cpu().numpy()
+    return np.concatenate([host[r, : per_rank[r]] for r in range(world)]).astype(np.int64)
+
+
 def transition_counts(total_frames: int, world: int) -> List[int]:
     """Transitions produced per rank: rank 0 has no halo, so one fewer than its frame count."""
     out = []
@@ -112,7 +131,8 @@ def _lap(stats, key, t0):
 
 def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, transform_mode: str, camera_lock: bool,
                       strength: float, smooth: float, keep_fov: float, padding_rgb, frame_rate: float, group=None,
-                      estimator: str = "flow", stats: Optional[Dict[str, float]] = None):
+                      estimator: str = "flow", stats: Optional[Dict[str, float]] = None, want_meta: bool = True,
+                      check_value_range: bool = True):
     """Sharded equivalent of `_stabilize_frames` (flow.py:213-640).
 
     local_frames: device tensor [n_local (+1 halo for rank > 0 that owns frames), H, W, 3] float32 -- this rank's frames
@@ -120,7 +140,11 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     Returns (frames [n_local,h,w,3], masks [n_local,h,w], meta) with the outputs resident on this rank's GPU; meta is
     identical on all ranks.  `stats` (optional dict) receives host wall-clock milliseconds per phase of this rank:
     estimate (launch + the fit's host sync), gather_fits, plan, warp_launch, meta, gather_counts -- the two gathers and
-    plan + meta are the replicated / serial part that bounds strong scaling."""
+    plan + meta are the replicated / serial part that bounds strong scaling.
+    want_meta=False: this rank skips building the JSON meta (returns None for it) but still joins both collectives --
+    a driver that needs the dict once asks rank 0 only.  check_value_range: F0's per-frame `max > 1.5 -> /255` rule
+    (stabilizer_utils.py:127-131) is applied to this rank's frames from the maxima the gray pass reports; it is a
+    per-frame rule, so no rank needs to know another rank's verdict."""
     import torch.distributed as dist
 
     from . import native
@@ -146,8 +170,18 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     estimator = resolve_flow_backend(estimator)
     estimate = _ESTIMATORS[estimator]
     t0 = time.perf_counter()
-    local_records = (estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0)) if local_frames.shape[0] >= 2
-                     else np.zeros((0, 3), native.FIT_DTYPE))
+    if local_frames.shape[0] >= 2:
+        peaks = [] if check_value_range else None
+        local_records = estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0), peaks_out=peaks)
+        if peaks:
+            rescaled, _ = hm.apply_value_range(local_frames, peaks[0])
+            if rescaled is not local_frames:   # 0..255 float frames on this rank: estimate again on the rescaled ones
+                local_frames = rescaled
+                local_records = estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0))
+    else:
+        if check_value_range and local_frames.shape[0] == 1:
+            local_frames, _ = hm.apply_value_range(local_frames, ctx.frame_range(local_frames))
+        local_records = np.zeros((0, 3), native.FIT_DTYPE)
     t0 = _lap(stats, "estimate", t0)
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)
     t0 = _lap(stats, "gather_fits", t0)
@@ -168,11 +202,11 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
         mask = torch.empty((0, out_h, out_w), dtype=torch.float32, device=own.device)
         counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
     t0 = _lap(stats, "warp_launch", t0)
-    meta = prepare_meta(plan)  # host JSON work overlaps this rank's warp kernel
+    meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel
     t0 = _lap(stats, "meta", t0)
-    all_counts = _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), frame_counts(total_frames, world),
-                              group=group, device=dev)
-    meta = complete_meta(meta, plan, all_counts.reshape(-1))
+    all_counts = _gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=dev is not None)
+    if want_meta:
+        meta = complete_meta(meta, plan, all_counts)
     _lap(stats, "gather_counts", t0)
     return dst, mask, meta
 

@@ -165,6 +165,18 @@ def rgb2gray_u8(rgb, fused_body=True):
     return out
 
 
+def frame_max(frames):
+    """Per-frame `float(arr.max())` of stabilizer_utils.py:127-131 for a clip [n,...] f32 (NaN-propagating)."""
+    frames = _f32(frames)
+    n = frames.shape[0]
+    out = np.empty(n, np.float32)
+    fn = lib().vo_frame_max
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]
+    fn.restype = None
+    fn(frames.ctypes.data, n, int(frames[0].size), out.ctypes.data)
+    return out
+
+
 def rgb2gray_f32(rgb, fused_body=True):
     """cv2.cvtColor(rgb f32, COLOR_RGB2GRAY) -> f32 [h,w]."""
     rgb = _f32(rgb)

@@ -32,6 +32,23 @@ void vo_rgb2gray_f32(const float* rgb, int h, int w, int fused_body, float* gray
     }
 }
 
+/* F0's range sniff, `float(arr.max())` per frame (stabilizer_utils.py:127-131): NaN-propagating like numpy's max */
+void vo_frame_max(const float* frames, int n, long long per_frame, float* out)
+{
+#pragma omp parallel for schedule(dynamic)
+    for (int f = 0; f < n; f++) {
+        const float* p = frames + (size_t)f * per_frame;
+        float m = -INFINITY;
+        int nan = 0;
+        for (long long k = 0; k < per_frame; k++) {
+            const float v = p[k];
+            nan |= (v != v);
+            m = v > m ? v : m;
+        }
+        out[f] = nan ? NAN : m;
+    }
+}
+
 void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray)
 {
     const float k0 = 0.299f, k1 = 0.587f, k2 = 0.114f;

@@ -36,6 +36,7 @@ void vo_crop_analysis(const float* matrices, int n, int sh, int sw, int oh, int 
 
 /* ---- gray + resize (vo_gray.c) ---- */
 void vo_rgb2gray_u8(const float* rgb, int h, int w, int fused_body, uint8_t* gray);
+void vo_frame_max(const float* frames, int n, long long per_frame, float* out);
 void vo_rgb2gray_f32(const float* rgb, int h, int w, int fused_body, float* gray);
 void vo_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 void vo_resize_linear_f32(const float* src, int sh, int sw, int cn, float* dst, int dh, int dw);

@@ -279,3 +279,31 @@ def test_fallback_backend_selection(pkg, monkeypatch):
         mats, modes, confs, resids, active = fp.select_transitions(table, requested)
         assert modes == ["translation"] * 4 and active == "translation" and confs == [0.9, 0.8, 0.7, 0.6] and resids == [0.0] * 4
         assert mats[:, 0, 2].tolist() == [1.5, -2.0, 0.25, 3.0]
+
+
+def test_bench_multi_gpu_launcher_spawns_children_not_exec(monkeypatch, tmp_path):
+    """`python bench.py --gpus N` without a torchrun environment (how the driver called `--gpus 1` in round 1) must
+    start the N ranks itself -- as a CHILD `torch.distributed.run` process, before anything touches the GPU, never an
+    exec (an exec from a GPU-initialised process takes the box down) -- and hand back the child's exit code."""
+    import importlib
+    import subprocess
+
+    import bench
+
+    importlib.reload(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert bench.main() == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    src = (ROOT / "bench.py").read_text()
+    assert "os.exec" not in src and "execv" not in src
