@@ -231,7 +231,7 @@ def apply_motion(
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
     if context.range_pending:   # F0's per-frame range sniff, on the device (stabilizer_utils.py:127-131)
-        if hm.resolve_value_range(context, ctx.frame_range(device_frames)):
+        if hm.resolve_value_range(context, ctx.frame_range(device_frames), ctx):
             device_frames = context.device_batch(ctx)
     frames, masks, result_meta = apply_motion_on_device(
         ctx, device_frames, 0, motion, meta, padding_rgb, framing_mode=framing_mode, interpolation=interpolation,

@@ -136,6 +136,7 @@ int vstab_create(vstab_ctx** out, int device)
     ctx->device = device;
     ctx->h_params.pinned_host = true;
     ctx->h_fit.pinned_host = true;
+    ctx->h_xfer.pinned_host = true;
     VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_params_free, hipEventDisableTiming));
     VSTAB_HIP(hipEventRecord(ctx->ev_params_free, nullptr));
     {
@@ -166,6 +167,10 @@ int vstab_destroy(vstab_ctx* ctx)
     for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
     if (ctx->h_status) (void)hipHostFree(const_cast<int*>(ctx->h_status));
+    if (ctx->xfer_stream) { (void)hipStreamSynchronize(ctx->xfer_stream); (void)hipStreamDestroy(ctx->xfer_stream); }
+    for (auto& ev : ctx->ev_xfer) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_xfer_sync) (void)hipEventDestroy(ctx->ev_xfer_sync);
+    ctx->h_xfer.release();
     delete ctx;
     return 0;
 }

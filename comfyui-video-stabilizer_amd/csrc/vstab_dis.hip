@@ -641,6 +641,26 @@ extern "C" void vstab_dis_dbg(long long* p) { g_dis_dbg = p; }
 #else
 #define FUSED_MARK(i)
 #endif
+// f32 division as hipcc emits it under -fhip-fp32-correctly-rounded-divide-sqrt, split so that quotients with a common
+// denominator share its refined reciprocal: the compiler's sequence is
+//   y0 = v_rcp(b); y = fma(fma(-b, y0, 1), y0, y0);  q0 = a*y; q1 = fma(fma(-b, q0, a), y, q0); q = fma(fma(-b, q1, a), y, q1)
+// wrapped in v_div_scale (rescales operands only when the denominator is denormal / huge or the numerator's exponent is
+// below 2^-104) and v_div_fixup (NaN / inf / zero cases).  For the linear system of the variational refinement the
+// denominators are >= zeta^2 = 0.01 and <= ~1e6 and the numerators are 0 or >= ~1e-20, where both wrappers are the
+// identity, so `div_shared(a, b, rcp_refined(b))` produces the bits of `a / b` (the oracle's IEEE division) with 5
+// instead of 11 instructions per additional numerator -- 18 of the 20 divisions per pixel share three denominators.
+__device__ __forceinline__ float rcp_refined(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float div_shared(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
+}
+
 struct LevelArgs {
 #ifdef VSTAB_FUSED_TRACE
     long long* dbg;
@@ -792,23 +812,30 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
                             float a11, a12, a22, B1, B2;
                             {
                                 float derivNorm = Ix * Ix + Iy * Iy + a.zeta2;
+                                float yn = rcp_refined(derivNorm);
+#define DIVN(x) div_shared((x), derivNorm, yn)
                                 float Ik1z = Iz + Ix * du + Iy * dv;
-                                float weight = a.delta2 / __builtin_sqrtf(Ik1z * Ik1z / derivNorm + a.eps2);
-                                a11 = weight * (Ix * Ix / derivNorm) + a.zeta2;
-                                a12 = weight * (Ix * Iy / derivNorm);
-                                a22 = weight * (Iy * Iy / derivNorm) + a.zeta2;
-                                B1 = -weight * (Iz * Ix / derivNorm);
-                                B2 = -weight * (Iz * Iy / derivNorm);
+                                float weight = a.delta2 / __builtin_sqrtf(DIVN(Ik1z * Ik1z) + a.eps2);
+                                a11 = weight * DIVN(Ix * Ix) + a.zeta2;
+                                a12 = weight * DIVN(Ix * Iy);
+                                a22 = weight * DIVN(Iy * Iy) + a.zeta2;
+                                B1 = -weight * DIVN(Iz * Ix);
+                                B2 = -weight * DIVN(Iz * Iy);
                                 derivNorm = Ixx * Ixx + Ixy * Ixy + a.zeta2;
-                                float derivNorm2 = Iyy * Iyy + Ixy * Ixy + a.zeta2;
+                                yn = rcp_refined(derivNorm);
+                                const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + a.zeta2;
+                                const float yn2 = rcp_refined(derivNorm2);
+#define DIVN2(x) div_shared((x), derivNorm2, yn2)
                                 float Ik1zx = Ixz + Ixx * du + Ixy * dv;
                                 float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-                                weight = a.gamma2 / __builtin_sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + a.eps2);
-                                a11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-                                a12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-                                a22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-                                B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-                                B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+                                weight = a.gamma2 / __builtin_sqrtf(DIVN(Ik1zx * Ik1zx) + DIVN2(Ik1zy * Ik1zy) + a.eps2);
+                                a11 += weight * (DIVN(Ixx * Ixx) + DIVN2(Ixy * Ixy));
+                                a12 += weight * (DIVN(Ixx * Ixy) + DIVN2(Ixy * Iyy));
+                                a22 += weight * (DIVN(Ixy * Ixy) + DIVN2(Iyy * Iyy));
+                                B1 += -weight * (DIVN(Ixx * Ixz) + DIVN2(Ixy * Iyz));
+                                B2 += -weight * (DIVN(Ixy * Ixz) + DIVN2(Iyy * Iyz));
+#undef DIVN
+#undef DIVN2
                             }
                             // smoothness term, accumulated in OpenCV's red/black scatter order.  `color` IS the global
                             // checkerboard parity (gx + gy) & 1 of the pixel, so the order is known at compile time.

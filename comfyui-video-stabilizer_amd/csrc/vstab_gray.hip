@@ -121,20 +121,43 @@ __global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict_
     }
 }
 
+// stabilizer_utils.py:127-131 applied to a clip: frames whose maximum exceeds 1.5 are divided by 255 (IEEE f32
+// division, as numpy's `arr /= 255.0`), the others are copied; NaN maxima compare False.  Out of place: the caller's
+// tensor is never modified.
+__global__ __launch_bounds__(256) void value_range_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const float* __restrict__ frame_max, long long per_frame, long long total)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const float v = src[t];
+        dst[t] = (frame_max[t / per_frame] > 1.5f) ? v / 255.0f : v;
+    }
+}
+
 // per-row maximum of a clip without producing gray (Motion Apply has no estimation pass): one workgroup per source row
+// VEC: pieces are a multiple of 4 floats and 16-B aligned (checked by the host); otherwise plain 4-B loads
+template <bool VEC>
 __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ frames, float* __restrict__ row_max, int row_floats)
 {
     __shared__ float s_max[4];
     __shared__ int s_nan[4];
-    const float4* R = reinterpret_cast<const float4*>(frames + (size_t)blockIdx.x * row_floats);
+    const float* S = frames + (size_t)blockIdx.x * row_floats;
     float vmax = -INFINITY;
     int has_nan = 0;
-    const int nvec = row_floats / 4;   // rows are 16-B aligned whenever row_floats % 4 == 0 (checked by the host)
-    for (int k = threadIdx.x; k < nvec; k += 256) {
-        const float4 v = R[k];
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-        const float probe = (v.x + v.y) + (v.z + v.w);
-        has_nan |= (probe != probe) ? 1 : 0;
+    if (VEC) {
+        const float4* R = reinterpret_cast<const float4*>(S);
+        const int nvec = row_floats / 4;
+        for (int k = threadIdx.x; k < nvec; k += 256) {
+            const float4 v = R[k];
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
+            const float probe = (v.x + v.y) + (v.z + v.w);
+            has_nan |= (probe != probe) ? 1 : 0;
+        }
+    } else {
+        for (int k = threadIdx.x; k < row_floats; k += 256) {
+            const float v = S[k];
+            vmax = __builtin_fmaxf(vmax, v);
+            has_nan |= (v != v) ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -353,17 +376,30 @@ extern "C" int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int
     hipStream_t st = ctx->stream;
     // a frame is h*w*3 contiguous floats: cut it into pieces of a multiple of 4 floats that divides it evenly
     const long long per_frame = (long long)h * w * 3;
-    long long piece = 0;
-    for (long long cand : {(long long)w * 3, (long long)w * 3 * 2, (long long)w * 3 * 4, per_frame})
-        if (cand % 4 == 0 && per_frame % cand == 0 && (reinterpret_cast<uintptr_t>(frames) % 16) == 0) { piece = cand; break; }
-    VSTAB_REQUIRE(piece > 0, "vstab_frame_range: frames of %dx%d cannot be cut into 16-byte aligned pieces", w, h);
+    long long piece = (long long)w * 3;   // one source row per workgroup
+    bool vec = false;
+    for (long long cand : {(long long)w * 3, (long long)w * 3 * 2, (long long)w * 3 * 4})
+        if (cand % 4 == 0 && per_frame % cand == 0 && (reinterpret_cast<uintptr_t>(frames) % 16) == 0) { piece = cand; vec = true; break; }
     const long long pieces = per_frame / piece;
     VSTAB_REQUIRE((long long)n * pieces < 0x7fffffffLL && piece < 0x7fffffffLL, "vstab_frame_range: clip too large");
     if (ctx->d_range.reserve(sizeof(float) * (size_t)n * pieces)) return 1;
     float* row_max = static_cast<float*>(ctx->d_range.ptr);
     KernelTimer timer(ctx, "range");
-    hipLaunchKernelGGL(row_max_kernel, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
+    if (vec) hipLaunchKernelGGL(row_max_kernel<true>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
+    else hipLaunchKernelGGL(row_max_kernel<false>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
     hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces);
+    VSTAB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vstab_apply_value_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, const float* frame_max, float* out)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_apply_value_range: ctx is NULL");
+    VSTAB_REQUIRE(frames && frame_max && out, "vstab_apply_value_range: NULL pointer argument");
+    VSTAB_REQUIRE(n > 0 && h > 0 && w > 0, "vstab_apply_value_range: non-positive size");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const long long per_frame = (long long)h * w * 3, total = per_frame * n;
+    hipLaunchKernelGGL(value_range_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, frames, out, frame_max, per_frame, total);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }

@@ -62,6 +62,11 @@ struct vstab_ctx {
     // bit into it through d_status; the host reads h_status after any stream synchronisation at no cost.
     volatile int* h_status = nullptr;
     int* d_status = nullptr;
+    // bulk host <-> device transfers (vstab_xfer.hip): pinned ring, its events, a copy stream
+    ScratchBuf h_xfer;
+    hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_xfer_sync = nullptr;
+    hipStream_t xfer_stream = nullptr;
 };
 
 enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired

@@ -174,13 +174,13 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
         peaks = [] if check_value_range else None
         local_records = estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0), peaks_out=peaks)
         if peaks:
-            rescaled, _ = hm.apply_value_range(local_frames, peaks[0])
+            rescaled, _ = hm.apply_value_range(local_frames, peaks[0], ctx)
             if rescaled is not local_frames:   # 0..255 float frames on this rank: estimate again on the rescaled ones
                 local_frames = rescaled
                 local_records = estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0))
     else:
         if check_value_range and local_frames.shape[0] == 1:
-            local_frames, _ = hm.apply_value_range(local_frames, ctx.frame_range(local_frames))
+            local_frames, _ = hm.apply_value_range(local_frames, ctx.frame_range(local_frames), ctx)
         local_records = np.zeros((0, 3), native.FIT_DTYPE)
     t0 = _lap(stats, "estimate", t0)
     records = gather_fit_records(local_records, total_frames, group=group, device=dev)

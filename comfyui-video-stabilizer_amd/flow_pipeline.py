@@ -522,7 +522,7 @@ def _stabilize_frames(
     estimate = _ESTIMATORS[estimator]
     peaks = [] if context.range_pending else None
     fit_records = estimate(ctx, device_frames, working_size, transform_mode, peaks_out=peaks)
-    if peaks and hm.resolve_value_range(context, peaks[0]):
+    if peaks and hm.resolve_value_range(context, peaks[0], ctx):
         # F0 (stabilizer_utils.py:127-131): some frame turned out to be 0..255 float data.  The estimation above ran
         # optimistically on the tensor as given (the gray pass reported the per-frame maxima for free); the frames
         # have been rescaled now, so it is repeated on the rescaled clip.  0..1 input -- the ComfyUI IMAGE contract --

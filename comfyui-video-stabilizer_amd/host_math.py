@@ -60,7 +60,8 @@ class VideoContext:
         if t is None:
             t = torch.from_numpy(np.ascontiguousarray(np.stack(self.frames, axis=0), dtype=np.float32))
         if t.device != ctx.device:
-            t = t.to(ctx.device, non_blocking=True)
+            # CPU tensor (the ComfyUI case): pipelined pageable -> pinned -> HBM upload (native.Context.upload)
+            t = ctx.upload(t) if t.device.type == "cpu" else t.to(ctx.device, non_blocking=True)
         self.batch = t.contiguous()
         return self.batch
 
@@ -135,18 +136,28 @@ def _fast_batch(value: Any):
     return value.detach().contiguous()
 
 
-def apply_value_range(batch, peaks):
+def apply_value_range(batch, peaks, ctx=None):
     """stabilizer_utils.py:127-131 on a whole batch: frames whose maximum exceeds 1.5 are divided by 255 (float32).
     `peaks`: per-frame maxima (tensor on any device; NaN compares False, as `float(arr.max()) > 1.5` does).
-    Returns (batch -- a rescaled copy if anything changed, else the same tensor --, value_range of frame 0)."""
-    big = (peaks > 1.5).to(batch.device)
+    Returns (batch -- a rescaled copy if anything changed, else the same tensor --, value_range of frame 0).
+    A device batch is rescaled by the library (vstab_apply_value_range: IEEE float32 division like numpy's; a torch
+    division on the GPU need not round the same way), a host batch with NumPy."""
+    big = (peaks > 1.5).cpu()
     if bool(big.any()):
-        batch = batch.clone()
-        batch[big] = batch[big] / 255.0
+        if batch.device.type == "cpu":
+            out = batch.clone()
+            arr = out.numpy()
+            for i in np.nonzero(big.numpy())[0]:
+                arr[i] /= np.float32(255.0)
+            batch = out
+        else:
+            from . import native
+
+            batch = (ctx or native.default_context()).apply_value_range(batch, peaks)
     return batch, ("0_255" if bool(big[0]) else "0_1")
 
 
-def resolve_value_range(context: "VideoContext", peaks=None) -> bool:
+def resolve_value_range(context: "VideoContext", peaks=None, ctx=None) -> bool:
     """Settle a pending range sniff of context.batch.  `peaks` = per-frame maxima from a GPU pass, or None to compute
     them here with tensor ops (host paths that never reach a kernel: single-frame passthrough, crop bypass on CPU).
     Returns True if frames were rescaled, i.e. whatever was derived from the unscaled pixels must be recomputed."""
@@ -154,7 +165,7 @@ def resolve_value_range(context: "VideoContext", peaks=None) -> bool:
         return False
     if peaks is None:
         peaks = context.batch.reshape(context.batch.shape[0], -1).amax(dim=1)
-    new_batch, vrange = apply_value_range(context.batch, peaks)
+    new_batch, vrange = apply_value_range(context.batch, peaks, ctx)
     changed = new_batch is not context.batch
     context.batch = new_batch
     context.adapter.value_range = vrange
@@ -210,12 +221,19 @@ def _to_host(t):
     ordinary CPU tensor for every consumer, but keeps its pages locked while it lives -- hence opt-in."""
     import os
 
-    if t.device.type != "cpu" and os.environ.get("VSTAB_PINNED_OUTPUT", "0") not in ("", "0", "false", "False"):
+    if t.device.type == "cpu":
+        return t
+    if os.environ.get("VSTAB_PINNED_OUTPUT", "0") not in ("", "0", "false", "False"):
         out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         out.copy_(t, non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
         return out
-    return t.cpu()
+    # default: an ordinary (pageable) CPU tensor, filled through the library's pinned ring by several host threads while
+    # the DMA engine fetches the next chunk (vstab_download) -- 2x+ the rate of t.cpu(), which stages on one thread
+    from . import native
+
+    with torch.cuda.device(t.device):
+        return native.default_context().download(t)
 
 
 def _reconstruct_video(frames: Any, context: VideoContext) -> Any:

@@ -101,6 +101,8 @@ _SIGNATURES = {
     "vstab_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_last_kernel_ms": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float)]),
     "vstab_kernel_ms_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vstab_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vstab_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_warp_batch": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -125,6 +127,7 @@ _SIGNATURES = {
     "vstab_gray_downscale_range": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_frame_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_apply_value_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_dis_flow_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_dis_set_clip_start": (C.c_int, [C.c_void_p, C.c_int]),
@@ -272,6 +275,25 @@ class Context:
             frames = frames.to(self.device, non_blocking=True)
         return frames.contiguous()
 
+    # ------------------------------------------------------------------ node-boundary transfers
+    def upload(self, host_tensor):
+        """CPU tensor (pageable) -> new device tensor through the library's pinned ring (vstab_upload)."""
+        torch = self.torch
+        src = host_tensor.contiguous()
+        dst = torch.empty(src.shape, dtype=src.dtype, device=self.device)
+        self.use_torch_stream()
+        _check(self.lib.vstab_upload(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel() * src.element_size()), "vstab_upload")
+        return dst
+
+    def download(self, device_tensor):
+        """Device tensor -> new CPU tensor (pageable, as the reference returns) through the pinned ring (vstab_download)."""
+        torch = self.torch
+        src = device_tensor.contiguous()
+        dst = torch.empty(src.shape, dtype=src.dtype)
+        self.use_torch_stream()
+        _check(self.lib.vstab_download(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel() * src.element_size()), "vstab_download")
+        return dst
+
     # ------------------------------------------------------------------ warp
     def warp_batch(self, frames, matrices, out_size, interp="bilinear", border=(0.0, 0.0, 0.0),
                    subpix=None, want_mask=True, want_count=False, out=None, out_mask=None):
@@ -361,6 +383,19 @@ class Context:
         self.use_torch_stream()
         _check(self.lib.vstab_frame_range(self.handle, _dev_ptr(src), n, sh, sw * ch // 3, _dev_ptr(peaks)), "vstab_frame_range")
         return peaks
+
+    def apply_value_range(self, frames, peaks):
+        """stabilizer_utils.py:127-131 on a device clip: a NEW tensor with the frames whose maximum (peaks, device f32 [N])
+        exceeds 1.5 divided by 255 in IEEE float32, the others copied."""
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        out = torch.empty_like(src)
+        peaks = peaks.to(device=self.device, dtype=torch.float32).contiguous()
+        self.use_torch_stream()
+        _check(self.lib.vstab_apply_value_range(self.handle, _dev_ptr(src), n, sh, sw * ch // 3, _dev_ptr(peaks), _dev_ptr(out)),
+               "vstab_apply_value_range")
+        return out
 
     def dis_flow_batch(self, gray, sample_step=8, want_full=False, want_grid=True, clip_start=True):
         """gray u8 [N,h,w] (device) -> (flow [N-1,h,w,2] | None, grid_flow [N-1,gh,gw,2] | None).

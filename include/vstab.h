@@ -66,6 +66,17 @@ int vstab_set_timing(vstab_ctx* ctx, int enabled);
 int vstab_last_kernel_ms(vstab_ctx* ctx, const char* kind, float* ms_out);
 int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, int* launches);
 
+/* ---- F0 / F16: the node boundary's bulk transfers ---------------------------------------------
+ * ComfyUI hands CPU tensors in and takes CPU tensors back (nodes/stabilizer_utils.py:96-147, :200-221): 6.37 GB in and
+ * 8.49 GB out for a 256 x 1080p clip.  vstab_upload / vstab_download move `bytes` between ordinary (pageable) host
+ * memory and device memory through a ring of page-locked buffers filled / drained by several host threads
+ * (VSTAB_XFER_THREADS, default 8) while the DMA engine moves the previous chunk.
+ * vstab_upload returns when every byte has left host_src (the copy into dev_dst completes asynchronously; work
+ * enqueued afterwards on the context's stream is ordered behind it).  vstab_download starts after the work already
+ * enqueued on the context's stream and returns when host_dst is complete. */
+int vstab_upload(vstab_ctx* ctx, const void* host_src, void* dev_dst, size_t bytes);
+int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_dst, size_t bytes);
+
 /* ---- F13 / A3: per-frame warp with padding mask ---------------------------
  * Replaces the loop at nodes/video_stabilizer_flow.py:560-588 and
  * nodes/motion_apply.py:92-120:
@@ -137,6 +148,10 @@ int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, 
 int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w,
                                int work_h, int work_w, uint8_t* gray, float* frame_max);
 int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, float* frame_max);
+/* The rule itself, out of place: out[f] = frames[f] / 255 (IEEE float32 division, numpy's `arr /= 255.0`) where
+ * frame_max[f] > 1.5, else a copy.  frames, frame_max, out: dev.  The caller's tensor is never modified. */
+int vstab_apply_value_range(vstab_ctx* ctx, const float* frames, int n, int h, int w,
+                            const float* frame_max, float* out);
 
 /* ---- F3 (+F4): DIS dense optical flow over consecutive pairs ---------------
  * Replaces cv2.DISOpticalFlow (PRESET_MEDIUM, finestScale 2, patchSize 8,

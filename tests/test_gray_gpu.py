@@ -76,6 +76,11 @@ def test_range_sniff_from_the_gray_pass(ctx, case):
     assert got[0] == np.float32(300.5) and (n == 1 or np.isnan(got[1]))
     alone = ctx.frame_range(frames).cpu().numpy()
     assert np.array_equal(alone, want, equal_nan=True)
+    # the rule itself (vstab_apply_value_range): IEEE float32 division of the frames above 1.5, NaN maxima compare False
+    expect = frames.copy()
+    expect[0] = frames[0] / np.float32(255.0)
+    rescaled = ctx.apply_value_range(frames, peaks).cpu().numpy()
+    assert np.array_equal(rescaled, expect, equal_nan=True)
 
 
 def test_frame_range_at_full_size(ctx):

@@ -151,3 +151,23 @@ def test_odd_output_sizes_and_single_pixel_frames(ctx, oracle):
             dst, mask, cnt = ctx.warp_batch(frames, mats, (dw, dh), interp=interp, border=BORDER, want_count=True)
             assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
             assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
+
+
+@pytest.mark.parametrize("nbytes", [4, 1000, (4 << 20) - 4, (32 << 20), (32 << 20) * 5 + 12, (32 << 20) * 9 - 8])
+def test_pipelined_upload_download_round_trip(ctx, nbytes):
+    """vstab_upload / vstab_download (the node boundary's transfers through the pinned ring + host thread team): byte
+    exact for sizes below one ring slot, equal to it, wrapping the ring several times and ragged tails; a download
+    enqueued right after a kernel on the same stream sees its result."""
+    import torch
+
+    n = nbytes // 4
+    g = torch.Generator().manual_seed(nbytes % 1000)
+    host = torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int32)
+    dev = ctx.upload(host)
+    assert dev.is_cuda and torch.equal(dev.cpu(), host)
+    back = ctx.download(dev)
+    assert back.device.type == "cpu" and not back.is_pinned() and torch.equal(back, host)
+    bumped = dev + 1                       # stream-ordered producer, no synchronisation before the download
+    assert torch.equal(ctx.download(bumped), host + 1)
+    again = ctx.upload(host[: max(1, n // 3)])   # the ring is reused by a later call while nothing else synchronised
+    assert torch.equal(again.cpu(), host[: max(1, n // 3)])
