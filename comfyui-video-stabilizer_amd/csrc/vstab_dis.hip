@@ -676,6 +676,8 @@ struct LevelArgs {
     int P, h, w, ws, hs, nh, nw;
     int tiles_x, tiles_y;   // SOR tiling (LDS temporal blocking)
     int lds_plane;          // floats per LDS plane (max padded tile)
+    int parts;              // split launches: workgroups per pair of this launch (pixel slices, or tiles)
+    int it;                 // split launches: fixed-point iteration of a LEVEL_TILE launch
     double up_sx, up_sy;
     float alpha2, delta2, gamma2, zeta2, eps2, omega;
 };
@@ -699,15 +701,29 @@ constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour 
 // owned pixel sit in registers and never reach memory, all 10 half-sweeps run on-chip, and only the tile
 // interior is written back (double-buffered, because neighbouring tiles still need the old halo).
 // tempW of OpenCV (W + dW) is recomputed where needed instead of stored.
-__global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
+//
+// MODE: LEVEL_FUSED is that single launch -- one workgroup per pair keeps 255 pairs on 256 CUs busy for a whole
+// 256-frame clip.  A rank of a multi-GPU run (or a short clip) has far fewer pairs than the chip has CUs, and the
+// fused form would leave most of it idle for the same wall time; the SPLIT modes run the same phases as separate
+// launches whose grids also cover the work INSIDE a pair -- pixel slices for the per-pixel phases, the tiles of one
+// fixed-point iteration for the temporally blocked part (tiles of an iteration are independent: they read the
+// previous iteration's increment and write the other buffer) -- with the kernel boundary as the only
+// synchronisation.  Same code, same arithmetic, same bits (tests/test_dis_gpu.py runs both).
+enum { LEVEL_FUSED = 0, LEVEL_PRE = 1, LEVEL_DERIV1 = 2, LEVEL_DERIV2 = 3, LEVEL_TILE = 4, LEVEL_MERGE = 5, LEVEL_UPSAMPLE = 6 };
+
+template <int MODE>
+__global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
 {
 #ifdef VSTAB_FUSED_TRACE
     long long tprev_ = wall_clock64();
-    const bool prof_ = a.dbg && blockIdx.x == 7 && threadIdx.x == 0;
+    const bool prof_ = MODE == LEVEL_FUSED && a.dbg && blockIdx.x == 7 && threadIdx.x == 0;
 #endif
 
     extern __shared__ float vr_lds[];
-    const int pair = blockIdx.x;
+    constexpr bool FUSED = MODE == LEVEL_FUSED;
+    const int pair = FUSED ? (int)blockIdx.x : (int)blockIdx.x / a.parts;
+    const int part = FUSED ? 0 : (int)blockIdx.x % a.parts;      // pixel slice or tile of this workgroup
+    const int nparts = FUSED ? 1 : a.parts;
     const int h = a.h, w = a.w;
     const int npx = h * w;
     const long long base = (long long)pair * npx;
@@ -718,20 +734,24 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
     const VrBufs& b = a.vb;
     const float* __restrict__ U = a.U + base;
     const float* __restrict__ V = a.V + base;
-#define FOR_PX(...)                                                         \
-    for (int q_ = threadIdx.x; q_ < npx; q_ += blockDim.x) {                \
-        const int y = q_ / w, x = q_ - y * w;                               \
-        const long long t = base + q_;                                      \
-        (void)x; (void)y;                                                   \
-        __VA_ARGS__;                                                        \
-    }                                                                       \
-    __syncthreads();
-    FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
-    FUSED_MARK(0);
-    FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
-    FUSED_MARK(1);
-    FOR_PX(vr_deriv1_px(b, t, x, y, h, w))
-    FOR_PX(vr_deriv2_px(b, t, x, y, h, w))
+    // the pixels of this workgroup: all of the pair's (fused), or every nparts-th block of FUSED_T (split)
+#define FOR_PX(...)                                                                                   \
+    for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {   \
+        const int y = q_ / w, x = q_ - y * w;                                                         \
+        const long long t = base + q_;                                                                \
+        (void)x; (void)y;                                                                             \
+        __VA_ARGS__;                                                                                  \
+    }                                                                                                 \
+    if (FUSED) __syncthreads();
+    if (FUSED || MODE == LEVEL_PRE) {
+        // (a thread densifies and warps the SAME pixels, and the warp reads U,V of its own pixel only)
+        FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
+        FUSED_MARK(0);
+        FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
+        FUSED_MARK(1);
+    }
+    if (FUSED || MODE == LEVEL_DERIV1) { FOR_PX(vr_deriv1_px(b, t, x, y, h, w)) }
+    if (FUSED || MODE == LEVEL_DERIV2) { FOR_PX(vr_deriv2_px(b, t, x, y, h, w)) }
     FUSED_MARK(2);
 
     const float* __restrict__ pIx = b.Ix + base;   const float* __restrict__ pIy = b.Iy + base;
@@ -750,8 +770,16 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
     float* dIn_u = b.dU + base;  float* dIn_v = b.dV + base;
     float* dOut_u = b.tU + base; float* dOut_v = b.tV + base;
 
-    for (int it = 0; it < VAR_ITERS; it++) {
-        for (int tile = 0; tile < a.tiles_x * a.tiles_y; tile++) {
+    // split: one (iteration, tile) per workgroup; the increment ping-pong is a function of the iteration's parity
+    const int it_lo = FUSED ? 0 : a.it, it_hi = FUSED ? VAR_ITERS : a.it + 1;
+    const int tile_lo = FUSED ? 0 : part, tile_hi = FUSED ? a.tiles_x * a.tiles_y : part + 1;
+    if (!FUSED && (a.it & 1)) {
+        float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
+        tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
+    }
+    if (FUSED || MODE == LEVEL_TILE)
+    for (int it = it_lo; it < it_hi; it++) {
+        for (int tile = tile_lo; tile < tile_hi; tile++) {
             const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
             const int ix0 = (int)((long long)w * tx / a.tiles_x), ix1 = (int)((long long)w * (tx + 1) / a.tiles_x);
             const int iy0 = (int)((long long)h * ty / a.tiles_y), iy1 = (int)((long long)h * (ty + 1) / a.tiles_y);
@@ -913,17 +941,20 @@ __global__ __launch_bounds__(FUSED_T) void level_fused_kernel(LevelArgs a)
         tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
     }
     // mergeCheckerboard(W, tempW): W + dW of the last fixed-point iteration
-    for (int q_ = threadIdx.x; q_ < npx; q_ += blockDim.x) {
-        a.U[base + q_] = U[q_] + dIn_u[q_];
-        a.V[base + q_] = V[q_] + dIn_v[q_];
+    if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) { dIn_u = b.tU + base; dIn_v = b.tV + base; }   // where iteration VAR_ITERS-1 wrote
+    if (FUSED || MODE == LEVEL_MERGE) {
+        for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {
+            a.U[base + q_] = U[q_] + dIn_u[q_];
+            a.V[base + q_] = V[q_] + dIn_v[q_];
+        }
+        if (FUSED) __syncthreads();
     }
-    __syncthreads();
 #undef FOR_PX
     FUSED_MARK(7);
-    if (a.nextU != nullptr) {
+    if ((FUSED || MODE == LEVEL_UPSAMPLE) && a.nextU != nullptr) {
         const int nn = a.nh * a.nw;
         const long long nbase = (long long)pair * nn;
-        for (int q_ = threadIdx.x; q_ < nn; q_ += blockDim.x) {
+        for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < nn; q_ += nparts * (int)blockDim.x) {
             const int dy = q_ / a.nw, dx = q_ - dy * a.nw;
             upsample_px(a.U, a.V, a.nextU, a.nextV, base, nbase + q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
         }
@@ -1137,9 +1168,37 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         }
         const size_t vr_lds_bytes = sizeof(float) * 4 * (size_t)la.lds_plane;
         VSTAB_REQUIRE(vr_lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: SOR tile needs %zu B of LDS", vr_lds_bytes);
-        if (vr_lds_bytes > 64 * 1024)
-            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
-        hipLaunchKernelGGL(level_fused_kernel, dim3((unsigned)P), dim3(FUSED_T), vr_lds_bytes, st, la);
+        // One workgroup per pair fills the chip only when there are about as many pairs as CUs (a 256-frame clip);
+        // below that the phases run as separate launches that also spread over the pixels / tiles inside a pair.
+        // VSTAB_DIS_SPLIT = 0 | 1 forces a form (A/B measurement, tests); default: split below 3/4 of the CUs.
+        static const int n_cu = [&] { int v = 256; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device); return v; }();
+        bool split = 4 * P < 3 * n_cu;
+        if (const char* e = getenv("VSTAB_DIS_SPLIT")) split = atoi(e) != 0;
+        if (!split) {
+            if (vr_lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_kernel<LEVEL_FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
+            la.parts = 1;
+            hipLaunchKernelGGL(level_kernel<LEVEL_FUSED>, dim3((unsigned)P), dim3(FUSED_T), vr_lds_bytes, st, la);
+        } else {
+            const int px_parts = std::max(1, std::min(64, (g.h * g.w + FUSED_T - 1) / FUSED_T));
+            la.parts = px_parts;
+            hipLaunchKernelGGL(level_kernel<LEVEL_PRE>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
+            hipLaunchKernelGGL(level_kernel<LEVEL_DERIV1>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
+            hipLaunchKernelGGL(level_kernel<LEVEL_DERIV2>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
+            if (vr_lds_bytes > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_kernel<LEVEL_TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
+            la.parts = la.tiles_x * la.tiles_y;
+            for (int it = 0; it < VAR_ITERS; it++) {
+                la.it = it;
+                hipLaunchKernelGGL(level_kernel<LEVEL_TILE>, dim3((unsigned)(P * la.parts)), dim3(FUSED_T), vr_lds_bytes, st, la);
+            }
+            la.parts = px_parts;
+            hipLaunchKernelGGL(level_kernel<LEVEL_MERGE>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
+            if (la.nextU != nullptr) {
+                la.parts = std::max(1, std::min(64, (la.nh * la.nw + FUSED_T - 1) / FUSED_T));
+                hipLaunchKernelGGL(level_kernel<LEVEL_UPSAMPLE>, dim3((unsigned)(P * la.parts)), dim3(FUSED_T), 0, st, la);
+            }
+        }
         VSTAB_HIP(hipGetLastError());
     }
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <pthread.h>
+#include <sys/mman.h>
 #include <thread>
 
 namespace {
@@ -22,7 +23,7 @@ constexpr int SLOTS = 4;
 
 int xfer_threads()
 {
-    int t = 8;
+    int t = 16;
     if (const char* e = getenv("VSTAB_XFER_THREADS")) t = atoi(e);
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && t > hw) t = hw;
@@ -123,6 +124,15 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
     char* dst = static_cast<char*>(host_dst);
     const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
     Team team(bytes < (size_t(4) << 20) ? 1 : xfer_threads());
+    // A freshly allocated output tensor is untouched memory: every 4 KiB page faults on first write, which is what
+    // bounds this copy (not PCIe).  Ask for transparent huge pages on the 2 MiB-aligned interior -- 512x fewer faults
+    // where the kernel grants it, no effect otherwise.
+    if (bytes >= (size_t(8) << 20) && !(getenv("VSTAB_XFER_THP") && atoi(getenv("VSTAB_XFER_THP")) == 0)) {
+        const uintptr_t huge = uintptr_t(2) << 20;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + huge - 1) & ~(huge - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(huge - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    }
     auto issue = [&](size_t c) {
         const int s = (int)(c % SLOTS);
         const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);

@@ -70,7 +70,7 @@ int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, in
  * ComfyUI hands CPU tensors in and takes CPU tensors back (nodes/stabilizer_utils.py:96-147, :200-221): 6.37 GB in and
  * 8.49 GB out for a 256 x 1080p clip.  vstab_upload / vstab_download move `bytes` between ordinary (pageable) host
  * memory and device memory through a ring of page-locked buffers filled / drained by several host threads
- * (VSTAB_XFER_THREADS, default 8) while the DMA engine moves the previous chunk.
+ * (VSTAB_XFER_THREADS, default 16, capped at the core count) while the DMA engine moves the previous chunk.
  * vstab_upload returns when every byte has left host_src (the copy into dev_dst completes asynchronously; work
  * enqueued afterwards on the context's stream is ordered behind it).  vstab_download starts after the work already
  * enqueued on the context's stream and returns when host_dst is complete. */

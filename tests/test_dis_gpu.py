@@ -104,3 +104,19 @@ def test_expired_dependency_wait_is_reported(pkg):
     ctx.synchronize()
     assert torch.equal(grid, clean)
     ctx.close()
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("n,h,w", [(3, 270, 480), (4, 45, 73), (2, 540, 960)])
+def test_dis_split_and_fused_launch_forms_match_oracle(ctx, oracle, monkeypatch, split, n, h, w):
+    """The per-level work runs either as one fused launch (one workgroup per pair) or as split launches that also
+    spread over the pixels / tiles inside a pair (few pairs: a multi-GPU rank, a short clip).  Both forms must give
+    the oracle's bits; VSTAB_DIS_SPLIT forces the form (the default picks by the number of pairs)."""
+    import torch
+
+    monkeypatch.setenv("VSTAB_DIS_SPLIT", split)
+    gray, _ = moving_clip(n, h, w, seed=h + 1)
+    flow, grid = ctx.dis_flow_batch(torch.from_numpy(gray), sample_step=8, want_full=True, want_grid=True)
+    ref = oracle.dis_flow_clip(gray)
+    assert np.array_equal(flow.cpu().numpy(), ref)
+    assert np.array_equal(grid.cpu().numpy(), ref[:, ::8, ::8, :])

@@ -1,0 +1,26 @@
+"""Workload for the PMC passes of tools/pmc_dis.sh: two Flow passes (C2, 256 x 1080p) and one Motion Apply pass
+(C3 kind: bicubic, blur 0.5, 17 samples, 64 x 1080p) so that level_fused_kernel, pis2_kernel and the blur warp kernel
+each appear a few times.  Run directly under rocprofv3 (`-- python3 tools/pmc_target.py`)."""
+import json, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch
+import __graft_entry__ as graft
+graft.load_package()
+import bench
+from vstab_amd import apply_pipeline as ap, flow_pipeline as fp, host_math as hm, native
+
+ctx = native.Context(0)
+frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
+for _ in range(2):
+    r = fp._stabilize_frames(hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
+    del r
+meta = {"motion_meta": json.loads((ROOT / "tests" / "golden" / "shake_c3_256x1080p.json").read_text())}
+blk = meta["motion_meta"]
+blk["per_frame"] = blk["per_frame"][:64]
+blk["frame_count"] = 64
+r = ap.apply_motion(hm._normalize_video_input(frames[:64]), meta, (127, 127, 127), framing_mode="crop_and_pad", interpolation="bicubic",
+                    motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
+torch.cuda.synchronize()
+print("done")
