@@ -41,7 +41,7 @@ struct Team {
     void sync() { pthread_barrier_wait(&bar); }
     void copy_share(int me, char* dst, const char* src, size_t bytes) const
     {
-        const size_t part = ((bytes / members) + 63) & ~size_t(63);
+        const size_t part = (((bytes + members - 1) / members) + 63) & ~size_t(63);   // ceil: a tail shorter than the team is still copied
         const size_t lo = std::min(bytes, part * me), hi = std::min(bytes, part * (me + 1));
         if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
     }
