@@ -94,7 +94,8 @@ __device__ __forceinline__ void area_axis(int d, int ssize, double scale, AreaAx
     ax.n = k;
 }
 
-// mode 0: exact 2x2, 1: exact kx x ky integer boxes, 2: general
+// mode 0: exact 2x2, 1: exact kx x ky integer boxes, 2: general, 3: exact 4x4 boxes on dword-aligned rows (the 960x540 ->
+// 240x135 level of every 1080p / 4K clip: four dword loads and four v_sad_u8 per output instead of sixteen byte loads)
 __global__ __launch_bounds__(256) void area_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n, int sh,
                                                       int sw, int dh, int dw, int mode, int kx, int ky, double scale_x,
                                                       double scale_y)
@@ -110,6 +111,13 @@ __global__ __launch_bounds__(256) void area_u8_kernel(const uint8_t* __restrict_
         if (mode == 0) {
             const uint8_t* s0 = S + (size_t)(2 * y) * sw + 2 * x;
             o = (s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2;
+        } else if (mode == 3) {
+            const unsigned* p = reinterpret_cast<const unsigned*>(S + (size_t)(4 * y) * sw + 4 * x);
+            const int rs = sw >> 2;
+            unsigned sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum = __builtin_amdgcn_sad_u8(p[(size_t)j * rs], 0u, sum);
+            o = sat_u8_round((int)sum * (1.f / 16));
         } else if (mode == 1) {
             int sum = 0;
             for (int j = 0; j < ky; j++)
@@ -167,37 +175,29 @@ __global__ __launch_bounds__(256) void sobel_kernel(const uint8_t* __restrict__ 
     }
 }
 
-// precomputeStructureTensor, horizontal running sums: one thread per (frame,row)
-__global__ __launch_bounds__(64) void tensor_h_kernel(const short* __restrict__ Ix, const short* __restrict__ Iy, float* __restrict__ aux,
-                                                      int n, int h, int w, int ws)
+// precomputeStructureTensor, horizontal sums of every patch column position (frame, row, js): OpenCV keeps five f32
+// running sums per row (`sum += x[j]*x[j] - x[j-8]*x[j-8]`, integer increments added to a float).  Every value such a
+// sum ever takes is an integer below 2^24 (8 terms of at most 1020^2: Sobel of u8 is within +-1020), so each of those
+// float additions is exact and the running sum equals the plain integer window sum -- computed here independently per
+// output, no sequential chain (the vertical pass, whose sums exceed 2^24, does keep OpenCV's order).
+__global__ __launch_bounds__(256) void tensor_h_kernel(const short* __restrict__ Ix, const short* __restrict__ Iy, float* __restrict__ aux,
+                                                       int n, int h, int w, int ws)
 {
-    const long long rows = (long long)n * h;
+    const long long total = (long long)n * h * ws;
     const size_t plane = (size_t)n * h * ws;
-    GRID_STRIDE(t, rows) {
-        const short* xr = Ix + (size_t)t * w;
-        const short* yr = Iy + (size_t)t * w;
-        float* o = aux + (size_t)t * ws;
-        float s_xx = 0.f, s_yy = 0.f, s_xy = 0.f, s_x = 0.f, s_y = 0.f;
+    GRID_STRIDE(t, total) {
+        const int js = (int)(t % ws);
+        const long long row = t / ws;
+        const short* xr = Ix + (size_t)row * w + js * PSTR;
+        const short* yr = Iy + (size_t)row * w + js * PSTR;
+        int s_xx = 0, s_yy = 0, s_xy = 0, s_x = 0, s_y = 0;
+#pragma unroll
         for (int j = 0; j < PSZ; j++) {
-            s_xx += xr[j] * xr[j];
-            s_yy += yr[j] * yr[j];
-            s_xy += xr[j] * yr[j];
-            s_x += xr[j];
-            s_y += yr[j];
+            const int gx = xr[j], gy = yr[j];
+            s_xx += gx * gx; s_yy += gy * gy; s_xy += gx * gy; s_x += gx; s_y += gy;
         }
-        o[0] = s_xx; o[plane] = s_yy; o[2 * plane] = s_xy; o[3 * plane] = s_x; o[4 * plane] = s_y;
-        int js = 1;
-        for (int j = PSZ; j < w; j++) {
-            s_xx += (xr[j] * xr[j] - xr[j - PSZ] * xr[j - PSZ]);
-            s_yy += (yr[j] * yr[j] - yr[j - PSZ] * yr[j - PSZ]);
-            s_xy += (xr[j] * yr[j] - xr[j - PSZ] * yr[j - PSZ]);
-            s_x += (xr[j] - xr[j - PSZ]);
-            s_y += (yr[j] - yr[j - PSZ]);
-            if ((j - PSZ + 1) % PSTR == 0) {
-                o[js] = s_xx; o[plane + js] = s_yy; o[2 * plane + js] = s_xy; o[3 * plane + js] = s_x; o[4 * plane + js] = s_y;
-                js++;
-            }
-        }
+        float* o = aux + t;
+        o[0] = (float)s_xx; o[plane] = (float)s_yy; o[2 * plane] = (float)s_xy; o[3 * plane] = (float)s_x; o[4 * plane] = (float)s_y;
     }
 }
 
@@ -1025,7 +1025,8 @@ int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh,
     const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
     const bool fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
     VSTAB_REQUIRE(scale_x >= 1.0 && scale_y >= 1.0 && scale_x < 6.0 && scale_y < 6.0, "dis: area ratio %.3fx%.3f unsupported", scale_x, scale_y);
-    const int mode = fast ? ((isx == 2 && isy == 2) ? 0 : 1) : 2;
+    int mode = fast ? ((isx == 2 && isy == 2) ? 0 : 1) : 2;
+    if (mode == 1 && isx == 4 && isy == 4 && sw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) mode = 3;
     const long long items = (long long)n * dh * dw;
     hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for(items)), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
     VSTAB_HIP(hipGetLastError());
@@ -1108,7 +1109,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         const long long px = (long long)n * g.h * g.w;
         hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)n * (g.h + 32) * (g.w + 32))), dim3(256), 0, st, I[i], Iext[i], n, g.h, g.w);
         hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(px)), dim3(256), 0, st, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h, 64)), dim3(64), 0, st, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h * g.ws)), dim3(256), 0, st, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
         hipLaunchKernelGGL(tensor_v_kernel, dim3(grid_for(5LL * n * g.ws, 64)), dim3(64), 0, st, aux, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
     }
@@ -1170,9 +1171,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         VSTAB_REQUIRE(vr_lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: SOR tile needs %zu B of LDS", vr_lds_bytes);
         // One workgroup per pair fills the chip only when there are about as many pairs as CUs (a 256-frame clip);
         // below that the phases run as separate launches that also spread over the pixels / tiles inside a pair.
-        // VSTAB_DIS_SPLIT = 0 | 1 forces a form (A/B measurement, tests); default: split below 3/4 of the CUs.
+        // VSTAB_DIS_SPLIT = 0 | 1 forces a form (A/B measurement, tests); default: split below 7/8 of the CUs (measured crossover, profiles/r02_dis_launch_forms.md).
         static const int n_cu = [&] { int v = 256; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device); return v; }();
-        bool split = 4 * P < 3 * n_cu;
+        bool split = 8 * P < 7 * n_cu;
         if (const char* e = getenv("VSTAB_DIS_SPLIT")) split = atoi(e) != 0;
         if (!split) {
             if (vr_lds_bytes > 64 * 1024)

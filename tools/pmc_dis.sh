@@ -10,31 +10,38 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_dis_$i -- python3 $R/tools/pmc_target.py > $OUT/pass$i.log 2>&1 || echo "pass failed: $grp"
-  f=$(find /tmp/pmc_dis_$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && cp $f $OUT/pass${i}_counter_collection.csv
-  k=$(find /tmp/pmc_dis_$i -name "*kernel_trace.csv" | head -1)
-  [ -n "$k" ] && cp $k $OUT/pass${i}_kernel_trace.csv
 done
 python3 - <<PY
 import csv, glob, collections
+import re
+def short(name):
+    m = re.search(r"(level_kernel<\d+>|pis2_kernel<\d+>|warp_kernel<[^>]*>|gray_area_int_kernel<[^>]*>|fit_kernel|tensor_h_kernel|area_u8_kernel)", name)
+    return m.group(1).replace(", ", ",") if m else None
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob("$OUT/pass*_counter_collection.csv")):
+for f in sorted(glob.glob("/tmp/pmc_dis_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"]
-        for key in ("level_fused_kernel", "pis2_kernel", "warp_kernel", "gray_area_int_kernel", "fit_kernel"):
-            if key in name:
-                short = name.split("(")[0][-60:]
-                rows[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = short(r["Kernel_Name"])
+        if k:
+            # the finest-level dispatches dominate: keep every dispatch, the table reports the per-dispatch mean of the
+            # LARGEST grid size of each kernel (= finest level) separately from the mean over all
+            rows[k][r["Counter_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
 dur = collections.defaultdict(list)
-for f in sorted(glob.glob("$OUT/pass1_kernel_trace.csv")):
+for f in sorted(glob.glob("/tmp/pmc_dis_1/**/*kernel_trace.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0][-60:]
-        dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        k = short(r["Kernel_Name"])
+        if k:
+            dur[k].append((int(r.get("Grid_Size", 0) or r.get("Grid_Size_X", 0) or 0), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+def biggest(pairs):
+    g = max(p[0] for p in pairs)
+    v = [p[1] for p in pairs if p[0] == g]
+    return sum(v) / len(v), len(v)
+rows = {k: {c: biggest(v) for c, v in cs.items()} for k, cs in rows.items()}
+dur = {k: biggest(v) for k, v in dur.items()}
 with open("$R/gpurun_out/${TAG}_pmc_kernels.csv", "w") as out:
     counters = sorted({c for v in rows.values() for c in v})
-    out.write("kernel,dispatches,avg_us_under_pmc," + ",".join(counters) + "\n")
+    out.write("kernel(largest grid = finest level),dispatches,avg_us_under_pmc," + ",".join(counters) + "\n")
     for name, cs in sorted(rows.items()):
-        d = dur.get(name, [])
-        out.write(f"{name},{max(len(v) for v in cs.values())},{(sum(d)/len(d) if d else 0):.1f}," + ",".join(f"{sum(cs[c])/len(cs[c]):.6g}" if cs.get(c) else "" for c in counters) + "\n")
+        d = dur.get(name, (0.0, 0))
+        out.write(f"{name},{max(v[1] for v in cs.values())},{d[0]:.1f}," + ",".join(f"{cs[c][0]:.6g}" if cs.get(c) else "" for c in counters) + "\n")
 print(open("$R/gpurun_out/${TAG}_pmc_kernels.csv").read())
 PY
