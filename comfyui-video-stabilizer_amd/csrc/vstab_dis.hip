@@ -238,50 +238,53 @@ __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ 
 // apart: acc_r = acc_(r-1) + s_r is one bank-masked `row_shr:4` DPP add per row, in row order.  Patch rows 0-3 are
 // DPP row 0 (2 for the upper half-wave), rows 4-7 DPP row 1 (3): the hop from lanes 12-15 to lanes 16-19 goes
 // through v_permlane16_swap (vdst row 1 <- src row 0) + a `row_ror:4` add.  The fold is two quad_perm adds.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_fetch(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-
-// one chain step on N independent sums: x[bank] += x[bank - 1] for the lanes of ROWMASK/BANKMASK only
-#define VSTAB_DPP_STEP(INSN_TAIL)                                                                             \
-    if constexpr (N == 4)                                                                                     \
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " INSN_TAIL "\n\tv_add_f32_dpp %1, %1, %1 " INSN_TAIL              \
-            "\n\tv_add_f32_dpp %2, %2, %2 " INSN_TAIL "\n\tv_add_f32_dpp %3, %3, %3 " INSN_TAIL                     \
-            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));                                                \
-    else                                                                                                      \
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " INSN_TAIL "\n\tv_add_f32_dpp %1, %1, %1 " INSN_TAIL              \
-            : "+v"(x[0]), "+v"(x[1]))
-
-// x[k] = this lane's (left + right) term of sum k; on return every lane holds its own patch's totals
+// x[k] = this lane's (left + right) term of sum k; on return every lane holds its own patch's totals.
+// The whole chain is ONE asm statement, so the distances between an instruction that writes a register and the DPP /
+// permlane instruction that reads it are fixed by this text, not by the scheduler: both need 2 wait states after a
+// VALU write (gfx950 hazard rules; inline asm is not seen by the hazard recogniser).  With four sums interleaved every
+// such pair is three instructions apart and only the first step needs an `s_nop`; with two sums one `s_nop 0` per step
+// supplies the missing wait state.  The hop between the DPP rows copies x to t, swaps t's odd rows with x's even rows
+// (v_permlane16_swap: t.row1 <- x.row0, t.row3 <- x.row2; x's even rows receive junk but are dead by then) and adds
+// through `row_ror:4`.
+#define S1(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x2\n\t"
+#define S2(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x4\n\t"
+#define S3(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x8\n\t"
+#define HOP(X, T) "v_add_f32_dpp " X ", " T ", " X " row_ror:4 row_mask:0xa bank_mask:0x1\n\t"
+#define S5(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x2\n\t"
+#define S6(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x4\n\t"
+#define S7(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x8\n\t"
+#define F1(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[2,3,0,1] row_mask:0xa bank_mask:0x8\n\t"
+#define F2(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[1,0,3,2] row_mask:0xa bank_mask:0x8\n\t"
+#define ALL4(M) M("%0") M("%1") M("%2") M("%3")
+#define ALL2(M) "s_nop 0\n\t" M("%0") M("%1")
 template <int N>
 __device__ __forceinline__ void patch_sums(float (&x)[N])
 {
     static_assert(N == 2 || N == 4, "two sums for an SSD evaluation, four for a descent step");
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x2");   // acc_1 = acc_0 + s_1   (acc_0 = 0 + s_0 = s_0)
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x4");   // acc_2
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0x5 bank_mask:0x8");   // acc_3
-    float t[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) {   // DPP row 1 (3) of t <- DPP row 0 (2) of x
-        const unsigned u = __builtin_bit_cast(unsigned, x[k]);
-        t[k] = __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(u, u, false, false)[0]);
+    if constexpr (N == 4) {
+        float t0, t1, t2, t3;
+        asm("s_nop 1\n\t"
+            ALL4(S1) ALL4(S2) ALL4(S3)                                                    // acc_1 .. acc_3 (acc_0 = s_0)
+            "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+            "v_permlane16_swap_b32 %4, %0\n\tv_permlane16_swap_b32 %5, %1\n\tv_permlane16_swap_b32 %6, %2\n\tv_permlane16_swap_b32 %7, %3\n\t"
+            HOP("%0", "%4") HOP("%1", "%5") HOP("%2", "%6") HOP("%3", "%7")                   // acc_4: lanes 16-19 <- lanes 12-15
+            ALL4(S5) ALL4(S6) ALL4(S7)                                                    // acc_7: lanes 28-31 (60-63) hold a0..a3
+            ALL4(F1) ALL4(F2)                                                             // (a0 + a2) + (a1 + a3)
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    } else {
+        float t0, t1;
+        asm("s_nop 0\n\t"
+            ALL2(S1) ALL2(S2) ALL2(S3)
+            "v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\t"
+            "v_permlane16_swap_b32 %2, %0\n\tv_permlane16_swap_b32 %3, %1\n\ts_nop 0\n\t"
+            HOP("%0", "%2") HOP("%1", "%3")
+            ALL2(S5) ALL2(S6) ALL2(S7) ALL2(F1) ALL2(F2)
+            : "+v"(x[0]), "+v"(x[1]), "=&v"(t0), "=&v"(t1));
     }
-    if constexpr (N == 4)                                      // acc_4 = acc_3 + s_4: lanes 16-19 <- lanes 12-15
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %4, %0 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %1, %5, %1 row_ror:4 row_mask:0xa bank_mask:0x1"
-            "\n\tv_add_f32_dpp %2, %6, %2 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %3, %7, %3 row_ror:4 row_mask:0xa bank_mask:0x1"
-            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
-    else
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %0 row_ror:4 row_mask:0xa bank_mask:0x1\n\tv_add_f32_dpp %1, %3, %1 row_ror:4 row_mask:0xa bank_mask:0x1"
-            : "+v"(x[0]), "+v"(x[1]) : "v"(t[0]), "v"(t[1]));
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x2");   // acc_5
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x4");   // acc_6
-    VSTAB_DPP_STEP("row_shr:4 row_mask:0xa bank_mask:0x8");   // acc_7: lanes 28-31 (60-63) hold a0..a3
-    VSTAB_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xa bank_mask:0x8");   // a0+a2, a1+a3, (a2+a0, a3+a1)
-    VSTAB_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xa bank_mask:0x8");   // (a0+a2) + (a1+a3) in all four lanes
-    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU
-    // instructions on the critical path of the gradient descent; a ds_bpermute is an LDS round trip
+    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU instructions
+    // on the critical path of the gradient descent.  (A ds_swizzle broadcast -- one LDS-crossbar instruction instead of
+    // 3-4 VALU ones -- was measured: the descent is a dependent chain per stripe, and the LDS round trip per step made
+    // DIS 0.8 ms slower per clip although the kernel issues fewer instructions; profiles/r02_dis_launch_forms.md.)
     const bool upper = (__lane_id() & 32) != 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -290,7 +293,17 @@ __device__ __forceinline__ void patch_sums(float (&x)[N])
         x[k] = upper ? t1 : t0;
     }
 }
-#undef VSTAB_DPP_STEP
+#undef S1
+#undef S2
+#undef S3
+#undef HOP
+#undef S5
+#undef S6
+#undef S7
+#undef F1
+#undef F2
+#undef ALL4
+#undef ALL2
 
 struct Bilin { int off; float w00, w01, w10, w11; };
 

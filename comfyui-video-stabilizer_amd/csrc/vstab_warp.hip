@@ -97,10 +97,10 @@ __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int
         const float wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
         const float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
         if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
-            const float* p = S + ((size_t)sy * sw + sx) * 3;
+            const float* p = S + ((unsigned)sy * (unsigned)sw + (unsigned)sx) * 3u;
             float r0[6], r1[6];
             __builtin_memcpy(r0, p, 24);
-            __builtin_memcpy(r1, p + (size_t)sw * 3, 24);
+            __builtin_memcpy(r1, p + (unsigned)sw * 3u, 24);
             o.r = r0[0] * w0 + r0[3] * w1 + r1[0] * w2 + r1[3] * w3;
             o.g = r0[1] * w0 + r0[4] * w1 + r1[1] * w2 + r1[4] * w3;
             o.b = r0[2] * w0 + r0[5] * w1 + r1[2] * w2 + r1[5] * w3;
@@ -113,10 +113,10 @@ __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int
         const bool x0ok = sx >= 0 && sx < sw, x1ok = sx + 1 >= 0 && sx + 1 < sw;
         const bool y0ok = sy >= 0 && sy < sh, y1ok = sy + 1 >= 0 && sy + 1 < sh;
         const Px bd = {b0, b1, b2};
-        const Px v0 = (x0ok && y0ok) ? load_px(S + ((size_t)sy * sw + sx) * 3) : bd;
-        const Px v1 = (x1ok && y0ok) ? load_px(S + ((size_t)sy * sw + sx + 1) * 3) : bd;
-        const Px v2 = (x0ok && y1ok) ? load_px(S + ((size_t)(sy + 1) * sw + sx) * 3) : bd;
-        const Px v3 = (x1ok && y1ok) ? load_px(S + ((size_t)(sy + 1) * sw + sx + 1) * 3) : bd;
+        const Px v0 = (x0ok && y0ok) ? load_px(S + ((unsigned)sy * (unsigned)sw + (unsigned)sx) * 3u) : bd;
+        const Px v1 = (x1ok && y0ok) ? load_px(S + ((unsigned)sy * (unsigned)sw + (unsigned)(sx + 1)) * 3u) : bd;
+        const Px v2 = (x0ok && y1ok) ? load_px(S + ((unsigned)(sy + 1) * (unsigned)sw + (unsigned)sx) * 3u) : bd;
+        const Px v3 = (x1ok && y1ok) ? load_px(S + ((unsigned)(sy + 1) * (unsigned)sw + (unsigned)(sx + 1)) * 3u) : bd;
         o.r = v0.r * w0 + v1.r * w1 + v2.r * w2 + v3.r * w3;
         o.g = v0.g * w0 + v1.g * w1 + v2.g * w2 + v3.g * w3;
         o.b = v0.b * w0 + v1.b * w1 + v2.b * w2 + v3.b * w3;
@@ -136,12 +136,12 @@ __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int
         const unsigned width1 = (unsigned)(sw - 3 > 0 ? sw - 3 : 0);
         const unsigned height1 = (unsigned)(sh - 3 > 0 ? sh - 3 : 0);
         if ((unsigned)x0 < width1 && (unsigned)y0 < height1) {
-            const float* p = S + ((size_t)y0 * sw + x0) * 3;
+            const float* p = S + ((unsigned)y0 * (unsigned)sw + (unsigned)x0) * 3u;
             float sr = 0.f, sg = 0.f, sb = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float row[12];
-                __builtin_memcpy(row, p + (size_t)i * sw * 3, 48);
+                __builtin_memcpy(row, p + (unsigned)i * (unsigned)sw * 3u, 48);
                 const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
                 const float tr = row[0] * w0 + row[3] * w1 + row[6] * w2 + row[9] * w3;
                 const float tg = row[1] * w0 + row[4] * w1 + row[7] * w2 + row[10] * w3;
@@ -165,7 +165,7 @@ __device__ __forceinline__ Px sample_q5(const float* __restrict__ S, int sh, int
             for (int j = 0; j < 4; j++) {
                 const int xx = x0 + j;
                 if (xx < 0 || xx >= sw) continue;
-                const Px v = load_px(S + ((size_t)yy * sw + xx) * 3);
+                const Px v = load_px(S + ((unsigned)yy * (unsigned)sw + (unsigned)xx) * 3u);
                 const float w = cy[i] * cx[j];
                 sr += (v.r - b0) * w;
                 sg += (v.g - b1) * w;
@@ -192,10 +192,10 @@ __device__ __forceinline__ Px sample_exact(const float* __restrict__ S, int sh, 
     const bool x0ok = ix >= 0 && ix < sw, x1ok = ix + 1 >= 0 && ix + 1 < sw;
     const bool y0ok = iy >= 0 && iy < sh, y1ok = iy + 1 >= 0 && iy + 1 < sh;
     const Px bd = {b0, b1, b2};
-    const Px p00 = (x0ok && y0ok) ? load_px(S + ((size_t)iy * sw + ix) * 3) : bd;
-    const Px p01 = (x1ok && y0ok) ? load_px(S + ((size_t)iy * sw + ix + 1) * 3) : bd;
-    const Px p10 = (x0ok && y1ok) ? load_px(S + ((size_t)(iy + 1) * sw + ix) * 3) : bd;
-    const Px p11 = (x1ok && y1ok) ? load_px(S + ((size_t)(iy + 1) * sw + ix + 1) * 3) : bd;
+    const Px p00 = (x0ok && y0ok) ? load_px(S + ((unsigned)iy * (unsigned)sw + (unsigned)ix) * 3u) : bd;
+    const Px p01 = (x1ok && y0ok) ? load_px(S + ((unsigned)iy * (unsigned)sw + (unsigned)(ix + 1)) * 3u) : bd;
+    const Px p10 = (x0ok && y1ok) ? load_px(S + ((unsigned)(iy + 1) * (unsigned)sw + (unsigned)ix) * 3u) : bd;
+    const Px p11 = (x1ok && y1ok) ? load_px(S + ((unsigned)(iy + 1) * (unsigned)sw + (unsigned)(ix + 1)) * 3u) : bd;
     float v0, v1;
     v0 = p00.r + ax * (p01.r - p00.r); v1 = p10.r + ax * (p11.r - p10.r); o.r = v0 + ay * (v1 - v0);
     v0 = p00.g + ax * (p01.g - p00.g); v1 = p10.g + ax * (p11.g - p10.g); o.g = v0 + ay * (v1 - v0);
@@ -346,16 +346,20 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     }
 
     if (active) {
-        const size_t row = ((size_t)frame * a.dh + y) * a.dw;
+        // per-frame bases are uniform (scalar registers); inside a frame 32-bit element offsets suffice (the host checks
+        // that a frame has fewer than 2^30 pixels), which keeps the address arithmetic out of 64-bit VALU multiplies
+        float* __restrict__ D = a.dst + (size_t)frame * a.dh * a.dw * 3;
+        float* __restrict__ Mk = WITH_MASK ? a.mask + (size_t)frame * a.dh * a.dw : nullptr;
+        const unsigned row = (unsigned)y * (unsigned)a.dw;
         typedef float f3 __attribute__((ext_vector_type(3)));
 #pragma unroll
         for (int p = 0; p < TILE_PX; p++) {
             if (p >= npx) continue;
-            const size_t pix = row + x0 + p * TILE_TX;
+            const unsigned pix = row + (unsigned)(x0 + p * TILE_TX);
             // 12 B per lane, consecutive lanes -> consecutive pixels: every store instruction writes whole lines
             f3 rgb = {acc[p][0], acc[p][1], acc[p][2]};
-            __builtin_memcpy(a.dst + pix * 3, &rgb, 12);
-            if (WITH_MASK) a.mask[pix] = mk[p];
+            __builtin_memcpy(D + pix * 3u, &rgb, 12);
+            if (WITH_MASK) Mk[pix] = mk[p];
         }
     }
 
@@ -424,6 +428,7 @@ int check_common(const char* who, vstab_ctx* ctx, const void* src, int n, int sh
     VSTAB_REQUIRE(src && mats && border && dst, "%s: NULL pointer argument", who);
     VSTAB_REQUIRE(n > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0, "%s: non-positive size (n=%d src=%dx%d out=%dx%d)", who, n, sw, sh, dw, dh);
     VSTAB_REQUIRE(sh <= 32767 && sw <= 32767, "%s: source larger than 32767 px is not representable in OpenCV's short maps", who);
+    VSTAB_REQUIRE((long long)sh * sw < (1LL << 30) && (long long)dh * dw < (1LL << 30), "%s: frames of 2^30 pixels or more are not supported (32-bit in-frame offsets)", who);
     VSTAB_REQUIRE(interp == VSTAB_INTERP_BILINEAR || interp == VSTAB_INTERP_BICUBIC, "%s: unknown interpolation %d", who, interp);
     VSTAB_REQUIRE(subpix == VSTAB_SUBPIX_Q5 || subpix == VSTAB_SUBPIX_EXACT, "%s: unknown subpix mode %d", who, subpix);
     VSTAB_REQUIRE(!(subpix == VSTAB_SUBPIX_EXACT && interp == VSTAB_INTERP_BICUBIC), "%s: exact sub-pixel mode exists for bilinear only", who);

@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "lib" / "libvstab.so"
+# VSTAB_LIB: another build of the library (A/B measurements of kernel variants inside one GPU session, tools/*.py)
+LIB_PATH = Path(os.environ["VSTAB_LIB"]).resolve() if os.environ.get("VSTAB_LIB") else _PKG_DIR / "lib" / "libvstab.so"
 
 INTERP = {"bilinear": 0, "bicubic": 1}
 SUBPIX = {"q5": 0, "exact": 1}
