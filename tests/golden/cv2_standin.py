@@ -204,6 +204,79 @@ def phaseCorrelate(a, b):
     return (float(tx), float(ty)), float(resp)
 
 
+# ---- Classic estimator primitives (nodes/video_stabilizer_classic.py:76-96) ------------------------------------------
+TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS = 1, 2
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3, **kw):
+    if mask is not None or kw:
+        raise NotImplementedError("cv2 stand-in: goodFeaturesToTrack without mask / extra options only")
+    _count("goodFeaturesToTrack")
+    pts = vo.good_features(image, maxCorners, qualityLevel, minDistance, blockSize)
+    return pts.reshape(-1, 1, 2) if len(pts) else None
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01), **kw):
+    if nextPts is not None or kw or winSize[0] != winSize[1]:
+        raise NotImplementedError("cv2 stand-in: calcOpticalFlowPyrLK without initial points / flags only")
+    _count("calcOpticalFlowPyrLK")
+    pts = np.asarray(prevPts, np.float32).reshape(-1, 2)
+    out, status = vo.lk_track(prevImg, nextImg, pts, winSize[0], maxLevel, criteria[1], criteria[2])
+    return out.reshape(-1, 1, 2), status.reshape(-1, 1), None
+
+
+# ---- drawing / synthesis helpers used ONLY by the reference's check scripts to make their test clips ----------------
+# (plain NumPy, no claim of matching OpenCV's rasteriser bit for bit: they produce inputs, not results under test)
+BORDER_REFLECT = 2
+
+
+def rectangle(img, pt1, pt2, color, thickness=-1):
+    if thickness != -1:
+        raise NotImplementedError("cv2 stand-in: filled rectangles only")
+    x0, y0 = pt1
+    x1, y1 = pt2
+    img[max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = np.asarray(color, img.dtype)[: img.shape[2]]
+    return img
+
+
+def circle(img, center, radius, color, thickness=-1):
+    if thickness != -1:
+        raise NotImplementedError("cv2 stand-in: filled circles only")
+    yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
+    inside = (xx - center[0]) ** 2 + (yy - center[1]) ** 2 <= radius * radius
+    img[inside] = np.asarray(color, img.dtype)[: img.shape[2]]
+    return img
+
+
+def getRotationMatrix2D(center, angle, scale):
+    a = np.deg2rad(angle)
+    alpha, beta = scale * np.cos(a), scale * np.sin(a)
+    return np.array([[alpha, beta, (1 - alpha) * center[0] - beta * center[1]],
+                     [-beta, alpha, beta * center[0] + (1 - alpha) * center[1]]], np.float64)
+
+
+def warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+    if flags != INTER_LINEAR or borderMode != BORDER_REFLECT:
+        raise NotImplementedError("cv2 stand-in: warpAffine(INTER_LINEAR, BORDER_REFLECT) only (clip synthesis of the check scripts)")
+    src = np.asarray(src, np.float32)
+    h, w = src.shape[:2]
+    full = np.vstack([np.asarray(M, np.float64), [0.0, 0.0, 1.0]])
+    inv = np.linalg.inv(full)
+    yy, xx = np.mgrid[0:dsize[1], 0:dsize[0]].astype(np.float64)
+    sx = inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]
+    sy = inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = (sx - x0)[..., None].astype(np.float32), (sy - y0)[..., None].astype(np.float32)
+
+    def reflect(i, n):   # BORDER_REFLECT: fedcba|abcdefgh|hgfedcb
+        i = np.mod(i, 2 * n)
+        return np.where(i >= n, 2 * n - 1 - i, i)
+
+    xa, xb, ya, yb = reflect(x0, w), reflect(x0 + 1, w), reflect(y0, h), reflect(y0 + 1, h)
+    out = (src[ya, xa] * (1 - fx) * (1 - fy) + src[ya, xb] * fx * (1 - fy) + src[yb, xa] * (1 - fx) * fy + src[yb, xb] * fx * fy)
+    return out.astype(np.float32)
+
+
 def install() -> types.ModuleType:
     """Register this module as `cv2` (and make `import cv2.optflow` fail the way a stock opencv-python-headless does)."""
     mod = sys.modules[__name__]

@@ -101,3 +101,22 @@ def test_host_planning_reproduces_reference_meta(pkg, oracle, name):
         golden = np.array([e["applied_matrix"] for e in want["stabilization_warp"]["per_frame"]], np.float32)
         assert np.allclose(recomposed, golden, rtol=0, atol=2e-5)
         assert fr["safe_region_size"][0] <= w + 1e-9 and fr["safe_region_size"][1] <= h + 1e-9
+
+
+@pytest.mark.skipif(not Path("/root/reference/scripts/check_motion_meta.py").exists(),
+                    reason="the reference tree exists in the build container only")
+def test_reference_check_scripts_pass_under_the_standin():
+    """Build container only: the reference's OWN functional check scripts (scripts/check_motion_meta.py,
+    check_crop_aspect_ratio.py, check_inverse_stabilization.py, check_node_schema.py) run against the reference's code with
+    the oracle-backed cv2 stand-in that produced the e2e fixtures, in a child process.  They assert, among others:
+    identity apply == input, blur determinism, tick counts N*S (+N), crop fallback, legacy inversion, crop aspect ratio
+    and zero padding for Classic and Flow, Motion Apply replay of the stabilizer's meta bit-identical, the expand ->
+    inverse round trip p99 <= 0.3 / mean <= 0.035.  If the stand-in misbehaved as a cv2, these would fail."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, str(Path(__file__).parent / "golden" / "run_reference_checks.py")], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    for script in ("check_motion_meta.py", "check_node_schema.py", "check_crop_aspect_ratio.py", "check_inverse_stabilization.py"):
+        assert f"{script}: exit code 0" in out.stdout, out.stdout[-2000:]
