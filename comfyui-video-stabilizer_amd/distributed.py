@@ -65,23 +65,28 @@ def _gather_rows(local: np.ndarray, counts: Sequence[int], group=None, device=No
     return np.concatenate([host[r, : counts[r]] for r in range(world)], axis=0)
 
 
-def _gather_counts(counts, per_rank: Sequence[int], group=None, on_device: bool = False) -> np.ndarray:
-    """all-gather of the per-frame padded-pixel counts.  With RCCL the int32 device tensor the warp kernel filled goes
-    into the collective as it is, stream-ordered behind the kernel (no host round trip before the exchange) and the
-    gathered table comes back in one D2H copy; with gloo (CPU tests) the counts travel as host rows."""
+def _start_gather_counts(counts, per_rank: Sequence[int], group=None, on_device: bool = False):
+    """all-gather of the per-frame padded-pixel counts, in two halves so that host work can run in between.
+    With RCCL the int32 device tensor the warp kernel filled goes into the collective as it is, stream-ordered behind the
+    kernel (no host round trip before the exchange): this call only ENQUEUES it; the returned function fetches the
+    gathered table with one D2H copy.  With gloo (CPU tests) the counts travel as host rows when the function is called."""
     import torch
     import torch.distributed as dist
 
     if not on_device:
-        return _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), per_rank, group=group).reshape(-1)
+        return lambda: _gather_rows(counts.cpu().numpy().astype(np.int64).reshape(-1, 1), per_rank, group=group).reshape(-1)
     world = dist.get_world_size(group)
     rows = max(max(per_rank), 1)
     padded = torch.zeros((rows,), dtype=torch.int32, device=counts.device)
     padded[: counts.shape[0]] = counts
     flat = torch.empty((world, rows), dtype=torch.int32, device=counts.device)
     dist.all_gather_into_tensor(flat, padded, group=group)
-    host = flat.cpu().numpy()
-    return np.concatenate([host[r, : per_rank[r]] for r in range(world)]).astype(np.int64)
+
+    def finish():
+        host = flat.cpu().numpy()
+        return np.concatenate([host[r, : per_rank[r]] for r in range(world)]).astype(np.int64)
+
+    return finish
 
 
 def transition_counts(total_frames: int, world: int) -> List[int]:
@@ -201,10 +206,11 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
         dst = torch.empty((0, out_h, out_w, 3), dtype=torch.float32, device=own.device)
         mask = torch.empty((0, out_h, out_w), dtype=torch.float32, device=own.device)
         counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
+    fetch_counts = _start_gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=dev is not None)
     t0 = _lap(stats, "warp_launch", t0)
-    meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel
+    meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel and the collective
     t0 = _lap(stats, "meta", t0)
-    all_counts = _gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=dev is not None)
+    all_counts = fetch_counts()
     if want_meta:
         meta = complete_meta(meta, plan, all_counts)
     _lap(stats, "gather_counts", t0)

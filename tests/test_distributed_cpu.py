@@ -75,9 +75,11 @@ def _worker(rank, world, port, total_frames, result_dir):
         plan = fp.plan_stabilization(NumpyTrajectoryCtx(), gathered, (192, 108), total_frames, "crop_and_pad", "similarity",
                                      False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0, 16.0)
         start, end = vd.shard_range(total_frames, world, rank)
-        local_counts = np.arange(start, end, dtype=np.int64).reshape(-1, 1) % 5
-        frame_counts = [vd.shard_range(total_frames, world, r)[1] - vd.shard_range(total_frames, world, r)[0] for r in range(world)]
-        all_counts = vd._gather_rows(local_counts, frame_counts).reshape(-1)
+        import torch
+
+        local_counts = torch.from_numpy((np.arange(start, end, dtype=np.int64) % 5).astype(np.int32))
+        fetch = vd._start_gather_counts(local_counts, vd.frame_counts(total_frames, world))   # host rows with gloo
+        all_counts = fetch()
         meta = fp.finish_meta(plan, all_counts)
         np.save(Path(result_dir) / f"final_{rank}.npy", np.stack(plan.final_matrices))
         import json
