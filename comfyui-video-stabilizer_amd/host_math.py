@@ -142,7 +142,7 @@ def apply_value_range(batch, peaks, ctx=None):
     Returns (batch -- a rescaled copy if anything changed, else the same tensor --, value_range of frame 0).
     A device batch is rescaled by the library (vstab_apply_value_range: IEEE float32 division like numpy's; a torch
     division on the GPU need not round the same way), a host batch with NumPy."""
-    big = (peaks > 1.5).cpu()
+    big = peaks.cpu() > 1.5   # one small D2H copy; the comparison runs on the host (no extra kernel launch in the step)
     if bool(big.any()):
         if batch.device.type == "cpu":
             out = batch.clone()
