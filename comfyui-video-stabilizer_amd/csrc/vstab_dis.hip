@@ -667,12 +667,17 @@ __device__ __forceinline__ float rcp_refined(float b)
     const float y0 = __builtin_amdgcn_rcpf(b);
     return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
 }
+__device__ __forceinline__ float div_shared(float a, float b, float y);
+// a / b for a single numerator in the same domain (8 instead of 11 instructions: no v_div_scale / v_div_fixup)
+__device__ __forceinline__ float div_plain(float a, float b);
 __device__ __forceinline__ float div_shared(float a, float b, float y)
 {
     const float q0 = a * y;
     const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
     return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
 }
+
+__device__ __forceinline__ float div_plain(float a, float b) { return div_shared(a, b, rcp_refined(b)); }
 
 struct LevelArgs {
 #ifdef VSTAB_FUSED_TRACE
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                     const float tur = U[qr] + dIn_u[qr], tvr = V[qr] + dIn_v[qr];
                     const float tud = U[qd] + dIn_u[qd], tvd = V[qd] + dIn_v[qd];
                     const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
-                    wv = a.alpha2 / __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2);
+                    wv = div_plain(a.alpha2, __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
                 }
                 lP[k] = f4_t{du, dv, wv, 0.f};
             }
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                                 float yn = rcp_refined(derivNorm);
 #define DIVN(x) div_shared((x), derivNorm, yn)
                                 float Ik1z = Iz + Ix * du + Iy * dv;
-                                float weight = a.delta2 / __builtin_sqrtf(DIVN(Ik1z * Ik1z) + a.eps2);
+                                float weight = div_plain(a.delta2, __builtin_sqrtf(DIVN(Ik1z * Ik1z) + a.eps2));
                                 a11 = weight * DIVN(Ix * Ix) + a.zeta2;
                                 a12 = weight * DIVN(Ix * Iy);
                                 a22 = weight * DIVN(Iy * Iy) + a.zeta2;
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
 #define DIVN2(x) div_shared((x), derivNorm2, yn2)
                                 float Ik1zx = Ixz + Ixx * du + Ixy * dv;
                                 float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-                                weight = a.gamma2 / __builtin_sqrtf(DIVN(Ik1zx * Ik1zx) + DIVN2(Ik1zy * Ik1zy) + a.eps2);
+                                weight = div_plain(a.gamma2, __builtin_sqrtf(DIVN(Ik1zx * Ik1zx) + DIVN2(Ik1zy * Ik1zy) + a.eps2));
                                 a11 += weight * (DIVN(Ixx * Ixx) + DIVN2(Ixy * Ixy));
                                 a12 += weight * (DIVN(Ixx * Ixy) + DIVN2(Ixy * Iyy));
                                 a22 += weight * (DIVN(Ixy * Ixy) + DIVN2(Iyy * Iyy));
@@ -927,8 +932,14 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             const float sigmaU = wl * pl.x + wq * pr.x + wu * pu.x + wq * pd.x;
                             const float sigmaV = wl * pl.y + wq * pr.y + wu * pu.y + wq * pd.y;
                             float du = pc.x, dv = pc.y;
-                            du += a.omega * ((sigmaU + cb1[color][u] - dv * c12[color][u]) / c11[color][u] - du);
-                            dv += a.omega * ((sigmaV + cb2[color][u] - du * c12[color][u]) / c22[color][u] - dv);
+                            // the two divisions in the split form of `/` (rcp_refined + div_shared, above): denominators >= zeta^2, so
+                            // v_div_scale / v_div_fixup are the identity; 8 instead of 11 instructions each.  The empty asm keeps
+                            // the reciprocal inside the loop: hoisted out of the ten half-sweeps it needs 20 more registers
+                            // and spills (profiles/r02_dis_launch_forms.md)
+                            float d11 = c11[color][u], d22 = c22[color][u];
+                            asm volatile("" : "+v"(d11), "+v"(d22));
+                            du += a.omega * (div_shared(sigmaU + cb1[color][u] - dv * c12[color][u], d11, rcp_refined(d11)) - du);
+                            dv += a.omega * (div_shared(sigmaV + cb2[color][u] - du * c12[color][u], d22, rcp_refined(d22)) - dv);
                             *reinterpret_cast<f2_t*>(lP + li) = f2_t{du, dv};
                         }
                         __builtin_amdgcn_sched_barrier(0);   // keep the owned pixels' updates apart (register pressure)

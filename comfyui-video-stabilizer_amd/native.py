@@ -169,6 +169,12 @@ def load_library():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback."
             )
+        # torch first: its wheel bundles its own libamdhip64.so.7 (+ libhsa-runtime64), and libvstab.so needs the same
+        # SONAME.  Loaded after torch, libvstab binds to torch's copy: one HIP runtime in the process, torch's streams
+        # and allocations are ours.  Loaded BEFORE torch it would pull in /opt/rocm's copy, torch would then find the
+        # SONAME taken and run on a runtime that does not match its other bundled libraries ("no ROCm-capable device").
+        import torch  # noqa: F401
+
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here means the ABI and the header diverged

@@ -307,3 +307,27 @@ def test_bench_multi_gpu_launcher_spawns_children_not_exec(monkeypatch, tmp_path
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     src = (ROOT / "bench.py").read_text()
     assert "os.exec" not in src and "execv" not in src
+
+
+def test_one_hip_runtime_in_the_process(pkg):
+    """libvstab.so and torch must share ONE libamdhip64: torch's wheel bundles its own copy under the same SONAME, and
+    whichever is loaded first wins.  If libvstab came first (e.g. build() followed by smoke() in one process), torch would
+    run on /opt/rocm's runtime next to its own bundled HSA runtime and report "no ROCm-capable device" on the GPU box
+    (seen in round 2).  load_library() therefore imports torch first; checked in a fresh interpreter that has not
+    imported torch before."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "g.load_package()\n"
+        "from vstab_amd import native\n"
+        "assert 'torch' not in sys.modules\n"
+        "native.load_library()\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps').read().split('\\n') if 'libamdhip64' in l})\n"
+        "print(libs)\n"
+        "assert len(libs) == 1 and '/torch/lib/' in libs[0], libs\n" % str(ROOT)
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
