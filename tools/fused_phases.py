@@ -1,4 +1,4 @@
-"""Per-phase time of one workgroup of level_fused_kernel at every pyramid level.
+"""Per-phase time of one workgroup of level_kernel<LEVEL_FUSED> at every pyramid level.
 
 Needs a developer build of libvstab (csrc: `rm build/vstab_dis.o; make EXTRA=-DVSTAB_FUSED_TRACE`), which accumulates
 wall_clock64 (100 MHz) differences between the phase barriers of workgroup 7.
