@@ -1198,7 +1198,11 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         // VSTAB_DIS_SPLIT = 0 | 1 forces a form (A/B measurement, tests); default: split below 7/8 of the CUs (measured crossover, profiles/r02_dis_launch_forms.md).
         static const int n_cu = [&] { int v = 256; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device); return v; }();
         bool split = 8 * P < 7 * n_cu;
-        if (const char* e = getenv("VSTAB_DIS_SPLIT")) split = atoi(e) != 0;
+        int forced = -1;
+        if (const char* e = getenv("VSTAB_DIS_SPLIT")) { forced = atoi(e); split = forced != 0; }
+        // a level that is a single tile has nothing to spread inside a pair: its ten split launches would only add
+        // launch boundaries to work that is latency-bound anyway (VSTAB_DIS_SPLIT=2 splits every level regardless)
+        if (split && forced != 2 && la.tiles_x * la.tiles_y == 1) split = false;
         if (!split) {
             if (vr_lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_kernel<LEVEL_FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));

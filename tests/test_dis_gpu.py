@@ -106,7 +106,7 @@ def test_expired_dependency_wait_is_reported(pkg):
     ctx.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split", ["0", "1", "2"])
 @pytest.mark.parametrize("n,h,w", [(3, 270, 480), (4, 45, 73), (2, 540, 960)])
 def test_dis_split_and_fused_launch_forms_match_oracle(ctx, oracle, monkeypatch, split, n, h, w):
     """The per-level work runs either as one fused launch (one workgroup per pair) or as split launches that also

@@ -17,14 +17,14 @@ frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
 gray = ctx.gray_downscale(frames, (960, 540))
 out = {}
 for n in (65, 129, 193, 256):
-    for split in ("0", "1"):
+    for split in ("0", "1", "2"):
         os.environ["VSTAB_DIS_SPLIT"] = split
         ts = []
         for r in range(6):
             ctx.dis_flow_batch(gray[:n], sample_step=8); torch.cuda.synchronize()
             if r >= 2: ts.append(ctx.last_kernel_ms("dis"))
         out[(n, split)] = round(float(np.median(ts)), 3)
-print(sys.argv[1] if len(sys.argv) > 1 else "default", {f"{n}f/{'split' if s == '1' else 'fused'}": v for (n, s), v in out.items()})
+print(sys.argv[1] if len(sys.argv) > 1 else "default", {f"{n}f/{ {'0': 'fused', '1': 'split-finest', '2': 'split-all'}[s]}": v for (n, s), v in out.items()})
 '''
 libs = sys.argv[1:] or [""]
 for lib in libs:
