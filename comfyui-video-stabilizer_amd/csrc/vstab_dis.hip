@@ -225,86 +225,14 @@ __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ 
 }
 
 // ---- patch inverse search ------------------------------------------------------------------
-// The four per-patch sums (sum d, sum d^2, sum d*Ix, sum d*Iy over the 8x8 patch) in OpenCV's own f32 association
-// (video/src/dis_flow.cpp, CV_SIMD128 branch of processPatchMeanNorm / computeSSDMeanNorm, patch size 8): one
+// The four per-patch sums (sum d, sum d^2, sum d*Ix, sum d*Iy over the 8x8 patch) are formed in OpenCV's own f32
+// association (video/src/dis_flow.cpp, CV_SIMD128 branch of processPatchMeanNorm / computeSSDMeanNorm, patch size 8): one
 // 4-lane accumulator; row after row adds (left half + right half) of its 8 terms -- accumulator lane l collects
 // columns l and l+4 -- and v_reduce_sum folds the lanes as (a0 + a2) + (a1 + a3).  These sums feed the branches
 // `SSD >= prev_SSD` and `cur_SSD < min_SSD`, where a last-bit difference moves a patch by a whole descent step
 // (round 1 used an XOR butterfly here; measured against this order it changed 0.4 % of the sampled flow vectors by
 // more than 1e-3 px, profiles/r02_dis_sum_order.md), so the association is part of the arithmetic contract.
-//
-// Mapping: a patch lives in one half-wave (32 lanes); lane (r, l) = 4*r + l holds the patch pixels (r, l) and
-// (r, l+4), so "left + right" is an in-lane add; the rows of accumulator lane l sit 4 lanes apart = one DPP bank
-// apart: acc_r = acc_(r-1) + s_r is one bank-masked `row_shr:4` DPP add per row, in row order.  Patch rows 0-3 are
-// DPP row 0 (2 for the upper half-wave), rows 4-7 DPP row 1 (3): the hop from lanes 12-15 to lanes 16-19 goes
-// through v_permlane16_swap (vdst row 1 <- src row 0) + a `row_ror:4` add.  The fold is two quad_perm adds.
-// x[k] = this lane's (left + right) term of sum k; on return every lane holds its own patch's totals.
-// The whole chain is ONE asm statement, so the distances between an instruction that writes a register and the DPP /
-// permlane instruction that reads it are fixed by this text, not by the scheduler: both need 2 wait states after a
-// VALU write (gfx950 hazard rules; inline asm is not seen by the hazard recogniser).  With four sums interleaved every
-// such pair is three instructions apart and only the first step needs an `s_nop`; with two sums one `s_nop 0` per step
-// supplies the missing wait state.  The hop between the DPP rows copies x to t, swaps t's odd rows with x's even rows
-// (v_permlane16_swap: t.row1 <- x.row0, t.row3 <- x.row2; x's even rows receive junk but are dead by then) and adds
-// through `row_ror:4`.
-#define S1(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x2\n\t"
-#define S2(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x4\n\t"
-#define S3(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0x5 bank_mask:0x8\n\t"
-#define HOP(X, T) "v_add_f32_dpp " X ", " T ", " X " row_ror:4 row_mask:0xa bank_mask:0x1\n\t"
-#define S5(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x2\n\t"
-#define S6(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x4\n\t"
-#define S7(X) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xa bank_mask:0x8\n\t"
-#define F1(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[2,3,0,1] row_mask:0xa bank_mask:0x8\n\t"
-#define F2(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[1,0,3,2] row_mask:0xa bank_mask:0x8\n\t"
-#define ALL4(M) M("%0") M("%1") M("%2") M("%3")
-#define ALL2(M) "s_nop 0\n\t" M("%0") M("%1")
-template <int N>
-__device__ __forceinline__ void patch_sums(float (&x)[N])
-{
-    static_assert(N == 2 || N == 4, "two sums for an SSD evaluation, four for a descent step");
-    if constexpr (N == 4) {
-        float t0, t1, t2, t3;
-        asm("s_nop 1\n\t"
-            ALL4(S1) ALL4(S2) ALL4(S3)                                                    // acc_1 .. acc_3 (acc_0 = s_0)
-            "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
-            "v_permlane16_swap_b32 %4, %0\n\tv_permlane16_swap_b32 %5, %1\n\tv_permlane16_swap_b32 %6, %2\n\tv_permlane16_swap_b32 %7, %3\n\t"
-            HOP("%0", "%4") HOP("%1", "%5") HOP("%2", "%6") HOP("%3", "%7")                   // acc_4: lanes 16-19 <- lanes 12-15
-            ALL4(S5) ALL4(S6) ALL4(S7)                                                    // acc_7: lanes 28-31 (60-63) hold a0..a3
-            ALL4(F1) ALL4(F2)                                                             // (a0 + a2) + (a1 + a3)
-            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
-    } else {
-        float t0, t1;
-        asm("s_nop 0\n\t"
-            ALL2(S1) ALL2(S2) ALL2(S3)
-            "v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\t"
-            "v_permlane16_swap_b32 %2, %0\n\tv_permlane16_swap_b32 %3, %1\n\ts_nop 0\n\t"
-            HOP("%0", "%2") HOP("%1", "%3")
-            ALL2(S5) ALL2(S6) ALL2(S7) ALL2(F1) ALL2(F2)
-            : "+v"(x[0]), "+v"(x[1]), "=&v"(t0), "=&v"(t1));
-    }
-    // hand each half its own total (lane 31 / lane 63): two scalar reads and a select are three cheap VALU instructions
-    // on the critical path of the gradient descent.  (A ds_swizzle broadcast -- one LDS-crossbar instruction instead of
-    // 3-4 VALU ones -- was measured: the descent is a dependent chain per stripe, and the LDS round trip per step made
-    // DIS 0.8 ms slower per clip although the kernel issues fewer instructions; profiles/r02_dis_launch_forms.md.)
-    const bool upper = (__lane_id() & 32) != 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[k]), 31));
-        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[k]), 63));
-        x[k] = upper ? t1 : t0;
-    }
-}
-#undef S1
-#undef S2
-#undef S3
-#undef HOP
-#undef S5
-#undef S6
-#undef S7
-#undef F1
-#undef F2
-#undef ALL4
-#undef ALL2
-
+// Its realisation on a wavefront is quarter_sums<N> below (pis4_kernel).
 struct Bilin { int off; float w00, w01, w10, w11; };
 
 __device__ __forceinline__ Bilin bilin_weights(int i, int j, float Ux, float Uy, float i_lo, float i_hi, float j_lo, float j_hi, int w_ext)
@@ -363,22 +291,78 @@ __device__ __forceinline__ void wait_progress(volatile int* counter, int need, i
         __hip_atomic_fetch_or(status, VSTAB_STATUS_PIS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ---- patch inverse search, two patch rows per wavefront ----------------------------------------
-// A wavefront holds TWO 8x8 patches (lanes 0-31 and 32-63; lane (r, l) of a half owns the pixels (r, l) and (r, l+4),
-// see patch_sums above) of two consecutive patch rows of a stripe; the second row trails the first by one patch,
-// which is exactly the raster dependency (left neighbour = own previous patch, vertical neighbour = the other half's
-// previous patch).  The weight / update arithmetic that is uniform over a patch is issued once for both patches.
-// Single-row stripes (coarsest levels, tiny images) run the same kernel with the upper half idle.
+// ---- patch inverse search, FOUR patch rows per wavefront ----------------------------------------
+// Two workgroups per frame pair, each owning 4 of OpenCV's 8 fixed stripes (the stripes are what makes the result
+// independent of the thread count); the padded I1 level image (<= 74 KB) and the block's sparse flow live in LDS, so the
+// dependent chain candidate -> bilinear window -> sums -> update never leaves the CU.  Inside a stripe the raster
+// recurrence (left + top in the forward pass, right + bottom in the backward pass) is kept exactly.
+// A wavefront holds four 8x8 patches, one per DPP row of 16 lanes, belonging to four consecutive patch rows of a stripe, each row trailing the previous one by one patch (the
+// raster dependency: left neighbour = own previous patch, vertical neighbour = the previous DPP row's previous patch).
+// Lane (rr, l) of a row owns the patch pixels (2rr, l), (2rr, l+4), (2rr+1, l), (2rr+1, l+4).  OpenCV's association of
+// the patch sums -- accumulator lane l adds (left + right) of row 0, 1, ... 7 in order -- becomes: x = left + right of
+// row 2rr, y = the same of row 2rr+1 (in-lane); bank 0: x += y; banks 1..3 in turn: x = x(bank-1) + x, then x += y;
+// fold; all inside one DPP row, so no cross-row hop, and the total reaches the row's 16 lanes with two `row_ror` moves.
+// Per sum 11 DPP instructions serve four patches, and the per-patch uniform arithmetic (bilinear weights, update) is
+// issued once for four patches: the kernel is VALU-issue-bound (profiles/r02_pmc_kernels.md).  Its predecessor held two
+// patches per wavefront (32 lanes each, 16 chain instructions per sum incl. a v_permlane16_swap hop between its two DPP
+// rows): DIS 4.29 -> 3.93 ms per 256-frame clip (profiles/r02_dis_launch_forms.md).
+#define Q_B0(X, Y) "v_add_f32_dpp " X ", " Y ", " X " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x1\n\t"
+#define Q_SH(X, K) "v_add_f32_dpp " X ", " X ", " X " row_shr:4 row_mask:0xf bank_mask:" K "\n\t"
+#define Q_AD(X, Y, K) "v_add_f32_dpp " X ", " Y ", " X " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:" K "\n\t"
+#define Q_F1(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x8\n\t"
+#define Q_F2(X) "v_add_f32_dpp " X ", " X ", " X " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x8\n\t"
+#define Q_C1(X) "v_mov_b32_dpp " X ", " X " row_ror:4 row_mask:0xf bank_mask:0x1\n\t"
+#define Q_C2(X) "v_mov_b32_dpp " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x6\n\t"
+// x[k] / y[k]: this lane's (left + right) terms of its two patch rows for sum k; on return x[k] = the patch total in all
+// 16 lanes of the DPP row.  One asm statement: with four sums interleaved every register written by one instruction is
+// read by a DPP operand three instructions later at the earliest (2 wait states needed); with two sums an `s_nop 0` per
+// step supplies the missing one.
+template <int N>
+__device__ __forceinline__ void quarter_sums(float (&x)[N], const float (&y)[N])
+{
+    static_assert(N == 2 || N == 4, "two sums for an SSD evaluation, four for a descent step");
+    if constexpr (N == 4) {
+        asm("s_nop 1\n\t"
+            Q_B0("%0", "%4") Q_B0("%1", "%5") Q_B0("%2", "%6") Q_B0("%3", "%7")
+            Q_SH("%0", "0x2") Q_SH("%1", "0x2") Q_SH("%2", "0x2") Q_SH("%3", "0x2")
+            Q_AD("%0", "%4", "0x2") Q_AD("%1", "%5", "0x2") Q_AD("%2", "%6", "0x2") Q_AD("%3", "%7", "0x2")
+            Q_SH("%0", "0x4") Q_SH("%1", "0x4") Q_SH("%2", "0x4") Q_SH("%3", "0x4")
+            Q_AD("%0", "%4", "0x4") Q_AD("%1", "%5", "0x4") Q_AD("%2", "%6", "0x4") Q_AD("%3", "%7", "0x4")
+            Q_SH("%0", "0x8") Q_SH("%1", "0x8") Q_SH("%2", "0x8") Q_SH("%3", "0x8")
+            Q_AD("%0", "%4", "0x8") Q_AD("%1", "%5", "0x8") Q_AD("%2", "%6", "0x8") Q_AD("%3", "%7", "0x8")
+            Q_F1("%0") Q_F1("%1") Q_F1("%2") Q_F1("%3") Q_F2("%0") Q_F2("%1") Q_F2("%2") Q_F2("%3")
+            Q_C1("%0") Q_C1("%1") Q_C1("%2") Q_C1("%3") Q_C2("%0") Q_C2("%1") Q_C2("%2") Q_C2("%3")
+            : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+    } else {
+#define Q_N "s_nop 0\n\t"
+        asm("s_nop 1\n\t"
+            Q_B0("%0", "%2") Q_B0("%1", "%3")
+            Q_N Q_SH("%0", "0x2") Q_SH("%1", "0x2") Q_N Q_AD("%0", "%2", "0x2") Q_AD("%1", "%3", "0x2")
+            Q_N Q_SH("%0", "0x4") Q_SH("%1", "0x4") Q_N Q_AD("%0", "%2", "0x4") Q_AD("%1", "%3", "0x4")
+            Q_N Q_SH("%0", "0x8") Q_SH("%1", "0x8") Q_N Q_AD("%0", "%2", "0x8") Q_AD("%1", "%3", "0x8")
+            Q_N Q_F1("%0") Q_F1("%1") Q_N Q_F2("%0") Q_F2("%1")
+            Q_N Q_C1("%0") Q_C1("%1") Q_N Q_C2("%0") Q_C2("%1")
+            : "+v"(x[0]), "+v"(x[1]) : "v"(y[0]), "v"(y[1]));
+#undef Q_N
+    }
+}
+#undef Q_B0
+#undef Q_SH
+#undef Q_AD
+#undef Q_F1
+#undef Q_F2
+#undef Q_C1
+#undef Q_C2
 
-// PIS2_PAIR_WAVES wavefronts per stripe share its row pairs round-robin (2 where a stripe has 3-4 rows, 1 for 2 rows).
-template <int PIS2_PAIR_WAVES>
-__global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void pis2_kernel(PisArgs a)
+// PIS4_WAVES wavefronts per stripe share its groups of four rows round-robin (1 up to four rows per stripe, else 2).
+template <int PIS4_WAVES>
+__global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_kernel(PisArgs a)
 {
     extern __shared__ unsigned char pis_lds[];
     const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int H = lane >> 5, hl = lane & 31, r = hl >> 2, c2 = hl & 3;
-    const int stripe = half * PIS_STRIPES_PER_BLOCK + wave / PIS2_PAIR_WAVES, pw = wave % PIS2_PAIR_WAVES;
+    const int Q = lane >> 4, t = lane & 15, rr = t >> 2, c2 = t & 3;
+    const int stripe = half * PIS_STRIPES_PER_BLOCK + wave / PIS4_WAVES, pw = wave % PIS4_WAVES;
     const int w = a.w, h = a.h, ws = a.ws, hs = a.hs;
     const int w_ext = w + 2 * DIS_BORDER, h_ext = h + 2 * DIS_BORDER;
     const int img_bytes = (w_ext * h_ext + 15) & ~15;
@@ -399,7 +383,7 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
     }
     __syncthreads();
     const int row_lo = min(stripe * a.stripe_sz, hs), row_hi = min((stripe + 1) * a.stripe_sz, hs);
-    const int nrows = row_hi - row_lo, npairs = (nrows + 1) >> 1;
+    const int nrows = row_hi - row_lo, ngroups = (nrows + 3) >> 2;
     const uint8_t* I0 = a.I + (size_t)pair * h * w;
     const short* Ix = a.Ix + (size_t)pair * h * w;
     const short* Iy = a.Iy + (size_t)pair * h * w;
@@ -411,37 +395,36 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
     const float j_lo = DIS_BORDER - PSZ + 1.0f, j_hi = DIS_BORDER + w - 1.0f;
     const int num_inner_iter = GD_ITERS / 2;
     const float nn = (float)(PSZ * PSZ);
-    const int lane_off2 = r * w_ext + c2;
+    const int lane_off4 = 2 * rr * w_ext + c2;
 
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
         const int start_is = (iter == 0) ? row_lo : row_hi - 1;
         const int start_js = (iter == 0) ? 0 : ws - 1;
         volatile int* done = (iter == 0) ? done0 : done1;
-        for (int k = pw; k < npairs; k += PIS2_PAIR_WAVES) {
-            const int row_a = start_is + dir * 2 * k;                 // leading row of the pair in this pass
-            const bool b_valid = 2 * k + 1 < nrows;
-            const int is = row_a + dir * H;
-            const bool row_ok = (H == 0) || b_valid;
+        for (int k = pw; k < ngroups; k += PIS4_WAVES) {
+            const int row_a = start_is + dir * 4 * k;                 // leading row of the group in this pass
+            const int nq = min(4, nrows - 4 * k);                     // rows in this group
+            const int is = row_a + dir * Q;
+            const bool row_ok = Q < nq;
             const int i = is * PSTR;
             if (iter == 1) {
-                // the backward pass starts from this row's forward-pass result; the pairing (hence the wavefront that
-                // produced it) may differ between the passes, so wait for the forward pass of both rows
-                wait_progress(done0 + row_a, ws, a.spin_limit, a.status);
-                if (b_valid) wait_progress(done0 + (row_a + dir), ws, a.spin_limit, a.status);
+                // the backward pass starts from each row's forward-pass result; the grouping (hence the wavefront that
+                // produced it) may differ between the passes, so wait for the forward pass of every row of the group
+                for (int q = 0; q < nq; q++) wait_progress(done0 + (row_a + dir * q), ws, a.spin_limit, a.status);
             }
-            for (int s = 0; s <= ws; s++) {
-                const int visited = s - H;                             // patches this half finished before this step
+            for (int s = 0; s < ws + nq - 1; s++) {
+                const int visited = s - Q;                             // patches this row finished before this step
                 const bool act = row_ok && visited >= 0 && visited < ws;
-                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, a.spin_limit, a.status);   // leading row's vertical neighbour (other wave)
+                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, a.spin_limit, a.status);   // leading row's vertical neighbour (previous group)
                 if (act) {
                     const int js = start_js + dir * visited;
                     const int j = js * PSTR;
                     const int sidx = is * ws + js;
-                    const size_t poff = (size_t)(i + r) * w + j + c2;     // columns c2 and c2 + 4 of patch row r
-                    const float i0a = (float)I0[poff], i0b = (float)I0[poff + 4];
-                    const float gxa = (float)Ix[poff], gxb = (float)Ix[poff + 4];
-                    const float gya = (float)Iy[poff], gyb = (float)Iy[poff + 4];
+                    const size_t p0 = (size_t)(i + 2 * rr) * w + j + c2, p1 = p0 + w;   // patch rows 2rr, 2rr+1; columns c2, c2+4
+                    const float i00 = (float)I0[p0], i01 = (float)I0[p0 + 4], i10 = (float)I0[p1], i11 = (float)I0[p1 + 4];
+                    const float gx00 = (float)Ix[p0], gx01 = (float)Ix[p0 + 4], gx10 = (float)Ix[p1], gx11 = (float)Ix[p1 + 4];
+                    const float gy00 = (float)Iy[p0], gy01 = (float)Iy[p0 + 4], gy10 = (float)Iy[p1], gy11 = (float)Iy[p1 + 4];
                     const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
                     const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
                     float Sxv, Syv;
@@ -452,34 +435,39 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                         Sxv = lSx[sidx];
                         Syv = lSy[sidx];
                     }
-#define PATCH_DIFF2(bw, d0_, d1_)                                                                          \
+#define PATCH_DIFF4(bw, d00_, d01_, d10_, d11_)                                                            \
     do {                                                                                                   \
-        const unsigned char* q_ = lI1 + (bw).off + lane_off2;                                              \
-        const float q00_ = (float)q_[0], q01_ = (float)q_[1], q04_ = (float)q_[4], q05_ = (float)q_[5];    \
-        const float q10_ = (float)q_[w_ext], q11_ = (float)q_[w_ext + 1];                                  \
-        const float q14_ = (float)q_[w_ext + 4], q15_ = (float)q_[w_ext + 5];                              \
-        d0_ = (bw).w00 * q00_ + (bw).w01 * q01_ + (bw).w10 * q10_ + (bw).w11 * q11_ - i0a;                 \
-        d1_ = (bw).w00 * q04_ + (bw).w01 * q05_ + (bw).w10 * q14_ + (bw).w11 * q15_ - i0b;                 \
+        const unsigned char* q_ = lI1 + (bw).off + lane_off4;                                              \
+        const float a0_ = (float)q_[0], a1_ = (float)q_[1], a4_ = (float)q_[4], a5_ = (float)q_[5];        \
+        const float b0_ = (float)q_[w_ext], b1_ = (float)q_[w_ext + 1];                                    \
+        const float b4_ = (float)q_[w_ext + 4], b5_ = (float)q_[w_ext + 5];                                \
+        const float c0_ = (float)q_[2 * w_ext], c1_ = (float)q_[2 * w_ext + 1];                            \
+        const float c4_ = (float)q_[2 * w_ext + 4], c5_ = (float)q_[2 * w_ext + 5];                        \
+        d00_ = (bw).w00 * a0_ + (bw).w01 * a1_ + (bw).w10 * b0_ + (bw).w11 * b1_ - i00;                    \
+        d01_ = (bw).w00 * a4_ + (bw).w01 * a5_ + (bw).w10 * b4_ + (bw).w11 * b5_ - i01;                    \
+        d10_ = (bw).w00 * b0_ + (bw).w01 * b1_ + (bw).w10 * c0_ + (bw).w11 * c1_ - i10;                    \
+        d11_ = (bw).w00 * b4_ + (bw).w01 * b5_ + (bw).w10 * c4_ + (bw).w11 * c5_ - i11;                    \
     } while (0)
-#define SSD_AT2(dst, ux, uy)                                                                               \
+#define SSD_AT4(dst, ux, uy)                                                                               \
     do {                                                                                                   \
         Bilin b_ = bilin_weights(i, j, (ux), (uy), i_lo, i_hi, j_lo, j_hi, w_ext);                         \
-        float e0_, e1_;                                                                                    \
-        PATCH_DIFF2(b_, e0_, e1_);                                                                         \
-        float ps_[2] = {e0_ + e1_, e0_ * e0_ + e1_ * e1_};                                                 \
-        patch_sums<2>(ps_);                                                                                \
-        dst = ps_[1] - ps_[0] * ps_[0] / nn;                                                               \
+        float e00_, e01_, e10_, e11_;                                                                      \
+        PATCH_DIFF4(b_, e00_, e01_, e10_, e11_);                                                           \
+        float px_[2] = {e00_ + e01_, e00_ * e00_ + e01_ * e01_};                                           \
+        const float py_[2] = {e10_ + e11_, e10_ * e10_ + e11_ * e11_};                                     \
+        quarter_sums<2>(px_, py_);                                                                         \
+        dst = px_[1] - px_[0] * px_[0] / nn;                                                               \
     } while (0)
                     float min_SSD, cur_SSD;
-                    SSD_AT2(min_SSD, Sxv, Syv);
+                    SSD_AT4(min_SSD, Sxv, Syv);
                     if (visited > 0) {
                         const float nx = lSx[sidx - dir], ny = lSy[sidx - dir];
-                        SSD_AT2(cur_SSD, nx, ny);
+                        SSD_AT4(cur_SSD, nx, ny);
                         if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                     }
-                    if (H == 1 || k > 0) {                              // a previously visited row exists in this pass
+                    if (Q >= 1 || k > 0) {                              // a previously visited row exists in this pass
                         const float nx = lSx[sidx - dir * ws], ny = lSy[sidx - dir * ws];
-                        SSD_AT2(cur_SSD, nx, ny);
+                        SSD_AT4(cur_SSD, nx, ny);
                         if (cur_SSD < min_SSD) { min_SSD = cur_SSD; Sxv = nx; Syv = ny; }
                     }
                     float cur_Ux = Sxv, cur_Uy = Syv;
@@ -487,13 +475,14 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                     if (__builtin_fabsf(detH) < DIS_EPS) detH = DIS_EPS;
                     const float invH11 = tyy / detH, invH12 = -txy / detH, invH22 = txx / detH;
                     float prev_SSD = DIS_INF;
-                    for (int t = 0; t < num_inner_iter; t++) {
+                    for (int tt = 0; tt < num_inner_iter; tt++) {
                         Bilin b = bilin_weights(i, j, cur_Ux, cur_Uy, i_lo, i_hi, j_lo, j_hi, w_ext);
-                        float d0, d1;
-                        PATCH_DIFF2(b, d0, d1);
-                        float ps[4] = {d0 + d1, d0 * d0 + d1 * d1, d0 * gxa + d1 * gxb, d0 * gya + d1 * gyb};
-                        patch_sums<4>(ps);
-                        const float sum_diff = ps[0], sum_sq = ps[1], sum_x = ps[2], sum_y = ps[3];
+                        float d00, d01, d10, d11;
+                        PATCH_DIFF4(b, d00, d01, d10, d11);
+                        float px[4] = {d00 + d01, d00 * d00 + d01 * d01, d00 * gx00 + d01 * gx01, d00 * gy00 + d01 * gy01};
+                        const float py[4] = {d10 + d11, d10 * d10 + d11 * d11, d10 * gx10 + d11 * gx11, d10 * gy10 + d11 * gy11};
+                        quarter_sums<4>(px, py);
+                        const float sum_diff = px[0], sum_sq = px[1], sum_x = px[2], sum_y = px[3];
                         const float dUx = sum_x - sum_diff * x_grad_sum / nn;
                         const float dUy = sum_y - sum_diff * y_grad_sum / nn;
                         const float SSD = sum_sq - sum_diff * sum_diff / nn;
@@ -504,13 +493,13 @@ __global__ __launch_bounds__(64 * PIS2_PAIR_WAVES * PIS_STRIPES_PER_BLOCK) void 
                         if (SSD >= prev_SSD) break;
                         prev_SSD = SSD;
                     }
-#undef SSD_AT2
-#undef PATCH_DIFF2
+#undef SSD_AT4
+#undef PATCH_DIFF4
                     {
                         const double ddx = (double)(cur_Ux - Sxv), ddy = (double)(cur_Uy - Syv);
                         if (__builtin_sqrt(ddx * ddx + ddy * ddy) <= (double)PSZ) { Sxv = cur_Ux; Syv = cur_Uy; }
                     }
-                    if (hl == 0) {
+                    if (t == 0) {
                         lSx[sidx] = Sxv;
                         lSy[sidx] = Syv;
                         __hip_atomic_store(const_cast<int*>(done + is), visited + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1155,15 +1144,15 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.status = ctx->d_status;
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
-        // two wavefronts per stripe share its row pairs where a stripe has 3-4 rows, one otherwise
-        if (pa.stripe_sz >= 3) {
+        // one wavefront per stripe walks its rows in groups of four; two share the groups where a stripe has more rows
+        if (pa.stripe_sz > 4) {
             if (lds_bytes > 64 * 1024)
-                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(pis2_kernel<2>, dim3((unsigned)P * 2), dim3(64 * 2 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis4_kernel<2>, dim3((unsigned)P * 2), dim3(64 * 2 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
         } else {
             if (lds_bytes > 64 * 1024)
-                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(pis2_kernel<1>, dim3((unsigned)P * 2), dim3(64 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(pis4_kernel<1>, dim3((unsigned)P * 2), dim3(64 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
         }
         LevelArgs la{};
 #ifdef VSTAB_FUSED_TRACE

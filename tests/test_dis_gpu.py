@@ -46,7 +46,9 @@ def moving_clip(n, h, w, seed=0):
 @pytest.mark.parametrize("n,h,w", [(3, 135, 240), (3, 270, 480), (2, 120, 213), (2, 100, 160),
                                    (4, 45, 73),    # tiny: OpenCV auto-selects finest 0 / coarsest 1
                                    (4, 40, 40),    # tiny + stateful: the first pair uses another pyramid than the rest
-                                   (2, 64, 96)])
+                                   (2, 64, 96),
+                                   (2, 600, 200),  # portrait: 36 patch rows at the finest level -> 5 rows per stripe (two wavefronts share a stripe)
+                                   (2, 960, 540)]) # the tallest working size: 59 patch rows, 8 per stripe
 def test_dis_matches_oracle(ctx, oracle, n, h, w):
     import torch
 
@@ -78,16 +80,16 @@ def test_expired_dependency_wait_is_reported(pkg):
     """Fail loudly: when a bounded LDS progress wait of the patch search expires, the kernel records it
     in the context's host-visible status word and the next synchronising call (the fit) returns non-zero with
     vstab_last_error() set -- instead of handing back a wrong flow with rc 0.  VSTAB_DEBUG_PIS_SPIN_LIMIT=0 makes every
-    not-yet-satisfied wait expire at once (a debug knob read per call; 960x540 so that the stripes of the finest levels
-    have several rows, i.e. real vertical dependencies).  The status word is cleared by the report, and the same
-    context computes the same flow as before afterwards."""
+    not-yet-satisfied wait expire at once (a debug knob read per call; a 540x960 portrait clip, whose stripes have eight
+    patch rows at the finest level: two wavefronts share a stripe and wait on each other's rows).  The status word is
+    cleared by the report, and the same context computes the same flow as before afterwards."""
     import os
 
     import torch
     from vstab_amd import native
 
     ctx = native.Context()
-    gray, _ = moving_clip(3, 540, 960, seed=7)
+    gray, _ = moving_clip(3, 960, 540, seed=7)
     dev = torch.from_numpy(gray).cuda()
     _, clean = ctx.dis_flow_batch(dev, sample_step=8)
     ctx.sample_fit_batch(clean, 8, "similarity")
