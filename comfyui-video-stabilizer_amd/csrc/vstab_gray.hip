@@ -3,8 +3,7 @@
 // Replaces nodes/stabilizer_utils.py:236-242 (_make_gray) and :271-276 (cv2.resize INTER_AREA).
 // This is the only estimation-stage pass that touches full-resolution data: 24.9 MB read per
 // 1080p frame, 0.5 MB written -> HBM-bound, one fused pass for the integer-ratio cases
-// (1080p -> 960x540 is 2x2, 4K -> 960x540 is 4x4).  Each thread produces 4 consecutive output
-// pixels: it streams 4*K RGB pixels (K*48 contiguous bytes) from each of K source rows.
+// (1080p -> 960x540 is 2x2, 4K -> 960x540 is 4x4): a lane per source pixel column, see gray_area_int_kernel.
 //
 // Gray arithmetic follows OpenCV's RGB2Gray<float>: an 8-lane FMA body
 // fma(b, 0.114, fma(g, 0.587, r*0.299)) and an unfused scalar tail for the last (w % 8) pixels
@@ -33,51 +32,71 @@ __device__ __forceinline__ int sat_u8_round(float v)
 }
 
 // Integer-ratio INTER_AREA (K x K boxes) fused with the gray conversion. K == 1: gray only.
-// One workgroup per output row; thread t produces the pixels t, t + 256, ...: the lanes of a wavefront read
-// CONSECUTIVE K-pixel groups (K * 12 B apart), so one load instruction touches K * 12 * 64 contiguous bytes
-// instead of 64 scattered 16-B pieces (the texture addresser, not HBM, was the limit with 4 pixels per thread).
+// One workgroup per output row, one SOURCE pixel column per lane: a lane reads its pixel (12 B) from each of the K rows
+// of the box and the K lanes of a box add up over DPP, so every load instruction of a wavefront covers 768 contiguous
+// bytes with no holes.  The frames are read once and never again by this pass: non-temporal loads (measured on
+// MI355X, profiles/r02_gray_forms.md: 256 x 1080p 1.09 -> 0.96 ms, 6.6 TB/s; 4K 0.82 -> 0.71 ms).  The launch picks a
+// workgroup size that divides the row into whole passes (640 threads for 1920 and 3840 columns).
 //
 // RANGE: the same pass also yields the largest sample of every source row it reads (NaN if the row holds one, as
 // numpy's max does) -- the value-range sniff of nodes/stabilizer_utils.py:127-131 (`float(arr.max()) > 1.5` per frame)
 // for free, instead of a second 24.9 MB read per frame.  Written per block to row_max[f * dh + y]; only valid when the
 // K x K boxes tile the whole source (the host checks dh * K == sh and dw * K == sw).
 template <int K, bool RANGE>
-__global__ __launch_bounds__(256) void gray_area_int_kernel(const float* __restrict__ frames, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(1024) void gray_area_int_kernel(const float* __restrict__ frames, uint8_t* __restrict__ out,
                                                              int n, int sh, int sw, int dh, int dw, int body,
                                                              float* __restrict__ row_max)
 {
-    __shared__ float s_max[4];
-    __shared__ int s_nan[4];
-    const int y = blockIdx.x % dh, f = blockIdx.x / dh;
+    __shared__ float s_max[16];
+    __shared__ int s_nan[16];
+    const int y = (int)blockIdx.x % dh, f = (int)blockIdx.x / dh;
     const float* rowbase = frames + ((size_t)f * sh + (size_t)y * K) * sw * 3;
     uint8_t* D = out + ((size_t)f * dh + y) * dw;
     float vmax = -INFINITY;
     int has_nan = 0;
-#pragma unroll 4
-    for (int x = threadIdx.x; x < dw; x += 256) {
-        int sum = 0;
-        const float* base = rowbase + (size_t)x * K * 3;
+    const int used = dw * K;   // == sw on the fused path
+    constexpr int U = 4 / K;   // columns per thread and pass: four 12-B loads in flight
+    typedef float f3_t __attribute__((ext_vector_type(3), aligned(4)));
+    for (int sx0 = threadIdx.x; sx0 < used; sx0 += U * blockDim.x) {
+        f3_t px[U][K];
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            float row[K * 3];
-            __builtin_memcpy(row, base + (size_t)j * sw * 3, sizeof(row));
+        for (int u = 0; u < U; u++) {
+            const int sx = sx0 + u * blockDim.x;
+            if (sx < used) {
 #pragma unroll
-            for (int i = 0; i < K; i++) {
-                sum += gray_u8(row[i * 3], row[i * 3 + 1], row[i * 3 + 2], (x * K + i) < body);
-                if (RANGE) {
-                    const float m3 = __builtin_fmaxf(__builtin_fmaxf(row[i * 3], row[i * 3 + 1]), row[i * 3 + 2]);
-                    vmax = __builtin_fmaxf(vmax, m3);
-                    // a + b + c is NaN iff one of them is (or inf - inf, which a frame does not sensibly hold)
-                    const float probe = row[i * 3] + row[i * 3 + 1] + row[i * 3 + 2];
-                    has_nan |= (probe != probe) ? 1 : 0;
+                for (int j = 0; j < K; j++)
+                    px[u][j] = __builtin_nontemporal_load(reinterpret_cast<const f3_t*>(rowbase + (size_t)j * sw * 3 + (size_t)sx * 3));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int sx = sx0 + u * blockDim.x;
+            if (sx < used) {
+                const bool fused = sx < body;
+                int sum = 0;
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const float cr = px[u][j].x, cg = px[u][j].y, cb = px[u][j].z;
+                    sum += gray_u8(cr, cg, cb, fused);
+                    if (RANGE) {
+                        vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fmaxf(cr, cg), cb));
+                        // a + b + c is NaN iff one of them is (or inf - inf, which a frame does not sensibly hold)
+                        const float probe = cr + cg + cb;
+                        has_nan |= (probe != probe) ? 1 : 0;
+                    }
+                }
+                // the K lanes of a box sit in one quad (blockDim.x and `used` are multiples of K): integer adds, any order
+                if (K >= 2) sum += __builtin_amdgcn_update_dpp(0, sum, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                if (K == 4) sum += __builtin_amdgcn_update_dpp(0, sum, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                if ((sx & (K - 1)) == 0) {
+                    int o;
+                    if (K == 1) o = sum;
+                    else if (K == 2) o = (sum + 2) >> 2;
+                    else o = sat_u8_round(sum * (1.f / (K * K)));
+                    D[sx / K] = (uint8_t)o;
                 }
             }
         }
-        int o;
-        if (K == 1) o = sum;
-        else if (K == 2) o = (sum + 2) >> 2;
-        else o = sat_u8_round(sum * (1.f / (K * K)));
-        D[x] = (uint8_t)o;
     }
     if (RANGE) {
 #pragma unroll
@@ -85,11 +104,13 @@ __global__ __launch_bounds__(256) void gray_area_int_kernel(const float* __restr
             vmax = __builtin_fmaxf(vmax, __shfl_down(vmax, off));
             has_nan |= __shfl_down(has_nan, off);
         }
+        const int nw = (blockDim.x + 63) >> 6;
         if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = vmax; s_nan[threadIdx.x >> 6] = has_nan; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
-            const int nn = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+            float m = s_max[0];
+            int nn = s_nan[0];
+            for (int k = 1; k < nw; k++) { m = __builtin_fmaxf(m, s_max[k]); nn |= s_nan[k]; }
             row_max[(size_t)f * dh + y] = nn ? NAN : m;
         }
     }
@@ -144,10 +165,12 @@ __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ 
     float vmax = -INFINITY;
     int has_nan = 0;
     if (VEC) {
-        const float4* R = reinterpret_cast<const float4*>(S);
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t* R = reinterpret_cast<const f4_t*>(S);
         const int nvec = row_floats / 4;
+#pragma unroll 4
         for (int k = threadIdx.x; k < nvec; k += 256) {
-            const float4 v = R[k];
+            const f4_t v = __builtin_nontemporal_load(R + k);   // read once by this pass (see gray_area_int_kernel)
             vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
             const float probe = (v.x + v.y) + (v.z + v.w);
             has_nan |= (probe != probe) ? 1 : 0;
@@ -271,13 +294,26 @@ static int gray_run(vstab_ctx* ctx, const float* frames, int n, int src_h, int s
     float* row_max = nullptr;
     int range_rows = 0;   // rows of row_max per frame once the gray pass has filled it
 
+    // workgroup size: the multiple of 64 (<= 1024) that covers a row of `cols` columns in whole passes with the fewest
+    // idle lane slots; ties go to the size nearest 640 (measured best for 1920 / 3840 columns)
+    auto threads_for = [](int cols) {
+        int best = 256;
+        long long best_cost = -1;
+        for (int t = 256; t <= 1024; t += 64) {
+            const long long cost = (long long)((cols + t - 1) / t) * t;
+            if (best_cost < 0 || cost < best_cost || (cost == best_cost && std::abs(t - 640) < std::abs(best - 640))) { best = t; best_cost = cost; }
+        }
+        if (const char* e = getenv("VSTAB_GRAY_THREADS")) best = atoi(e);   // A/B measurement (tools/gray_forms.py)
+        return best;
+    };
 #define LAUNCH_GRAY(K, ROWS, OUT)                                                                                         \
     do {                                                                                                                  \
+        const int threads = threads_for(src_w / K * K);                                                                   \
         if (row_max)                                                                                                      \
-            hipLaunchKernelGGL((gray_area_int_kernel<K, true>), dim3((unsigned)(n * (ROWS))), dim3(256), 0, st, frames, OUT, n, src_h, \
+            hipLaunchKernelGGL((gray_area_int_kernel<K, true>), dim3((unsigned)(n * (ROWS))), dim3(threads), 0, st, frames, OUT, n, src_h, \
                                src_w, (ROWS), src_w / K, body, row_max);                                                  \
         else                                                                                                              \
-            hipLaunchKernelGGL((gray_area_int_kernel<K, false>), dim3((unsigned)(n * (ROWS))), dim3(256), 0, st, frames, OUT, n, src_h, \
+            hipLaunchKernelGGL((gray_area_int_kernel<K, false>), dim3((unsigned)(n * (ROWS))), dim3(threads), 0, st, frames, OUT, n, src_h, \
                                src_w, (ROWS), src_w / K, body, row_max);                                                  \
         VSTAB_HIP(hipGetLastError());                                                                                     \
     } while (0)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC view of the VALU-bound kernels (DIS level_fused / pis2, blur warp): one bounded rocprofv3 pass per counter group,
+# PMC view of the VALU-bound kernels (DIS level_kernel / pis4, blur warp): one bounded rocprofv3 pass per counter group,
 # --pmc with --kernel-trace only (no other trace domain), program directly after `--`.
 #   usage: tools/pmc_dis.sh <tag>      -> gpurun_out/<tag>_pmc_kernels.csv (+ the raw per-dispatch csv of each pass)
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +15,7 @@ python3 - <<PY
 import csv, glob, collections
 import re
 def short(name):
-    m = re.search(r"(level_kernel<\d+>|pis2_kernel<\d+>|warp_kernel<[^>]*>|gray_area_int_kernel<[^>]*>|fit_kernel|tensor_h_kernel|area_u8_kernel)", name)
+    m = re.search(r"(level_kernel<\d+>|pis4_kernel<\d+>|warp_kernel<[^>]*>|gray_area_int_kernel<[^>]*>|fit_kernel|tensor_h_kernel|area_u8_kernel)", name)
     return m.group(1).replace(", ", ",") if m else None
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("/tmp/pmc_dis_*/**/*counter_collection.csv", recursive=True)):
