@@ -1,8 +1,8 @@
 """GPU parity: vstab_dis_flow_batch (HIP) vs oracle/vo_dis.c.
 
 Tolerance: bit-exact.  Both sides use the same operation order (FMA contraction off, correctly
-rounded f32 divide/sqrt, identical butterfly reduction for the patch sums), so every data-dependent
-branch of the inverse search takes the same path.  The independent check (known synthetic camera
+rounded f32 divide/sqrt, OpenCV's 4-lane row-accumulator association for the patch sums -- see
+tests/test_dis_sum_order_cpu.py), so every data-dependent branch of the inverse search takes the same path.  The independent check (known synthetic camera
 motion) bounds the end result without reference to OpenCV's intermediate values."""
 
 import numpy as np
@@ -60,6 +60,41 @@ def test_dis_matches_oracle(ctx, oracle, n, h, w):
     diff = np.abs(got - ref)
     assert np.array_equal(got, ref), f"max abs diff {diff.max()} at {np.unravel_index(diff.argmax(), diff.shape)}"
     assert np.array_equal(grid.cpu().numpy(), ref[:, ::8, ::8, :])
+
+
+def _content_clips(h, w):
+    """Clips that drive the rarely taken branches: zero gradients (determinant floor), pure noise (descent stops at once,
+    updates discarded), hard edges, saturated values, a jump far beyond a patch, identical frames."""
+    rng = np.random.default_rng(99)
+    yy, xx = np.mgrid[0:h, 0:w]
+    flat = np.full((3, h, w), 131, np.uint8)
+    flat[1] = 7
+    noise = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    bars = np.stack([(((xx + 9 * i) // 11 + (yy - 5 * i) // 17) % 2 * 255).astype(np.uint8) for i in range(3)])
+    base, _ = moving_clip(1, h + 80, w + 80, seed=5)
+    jump = np.stack([base[0, 40:40 + h, 40:40 + w], base[0, 3:3 + h, 75:75 + w], base[0, 40:40 + h, 40:40 + w]])
+    still = np.repeat(base[:, 10:10 + h, 10:10 + w], 3, axis=0)
+    sat = np.clip(base[0, :h, :w].astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)
+    sat = np.stack([sat, np.roll(sat, (2, -3), (0, 1)), np.roll(sat, (-1, 4), (0, 1))])
+    half = still.copy()
+    half[1, :, w // 2:] = noise[1, :, w // 2:]   # one half loses all correspondence
+    return {"flat": flat, "noise": noise, "bars": bars, "jump": jump, "still": still, "saturated": sat, "half_noise": half}
+
+
+@pytest.mark.parametrize("name", ["flat", "noise", "bars", "jump", "still", "saturated", "half_noise"])
+@pytest.mark.parametrize("h,w", [(135, 240), (150, 101)])
+def test_dis_content_edge_cases_match_oracle(ctx, oracle, name, h, w):
+    import torch
+
+    gray = np.ascontiguousarray(_content_clips(h, w)[name])
+    ref = oracle.dis_flow_clip(gray)
+    flow, _ = ctx.dis_flow_batch(torch.from_numpy(gray), sample_step=8, want_full=True, want_grid=True)
+    got = flow.cpu().numpy()
+    assert np.isfinite(ref).all()
+    diff = np.abs(got - ref)
+    assert np.array_equal(got, ref), f"{name}: max abs diff {diff.max()} at {np.unravel_index(diff.argmax(), diff.shape)}"
+    if name in ("flat", "still"):
+        assert np.abs(got[-1]).max() < (1e-3 if name == "still" else 1.0)
 
 
 def test_dis_recovers_known_translation(ctx):

@@ -29,6 +29,22 @@ def test_gray_downscale_matches_oracle(ctx, oracle, case):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("case", CASES[:4] + [(2, 40, 1000, (500, 20)), (1, 16, 2044, (511, 4))])
+def test_gray_out_of_range_samples_match_oracle(ctx, oracle, case):
+    """Samples outside [0, 1] (overshoot of an upstream bicubic resize, HDR-ish sources, infinities): the clip to
+    [0, 255] before the truncation decides; long rows = several passes of a workgroup over the row."""
+    n, h, w, work = case
+    rng = np.random.default_rng(w)
+    frames = rng.uniform(-0.6, 1.8, (n, h, w, 3)).astype(np.float32)
+    frames[0, 1, 2::7, 0] = np.inf
+    frames[0, 2, 3::5, 2] = -np.inf
+    frames[-1, 3, ::9, 1] = 1.0e30
+    ref = oracle.gray_for_estimation(frames, work)
+    got, peaks = ctx.gray_downscale(frames, work, want_range=True)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    assert np.array_equal(peaks.cpu().numpy(), frames.reshape(n, -1).max(axis=1))
+
+
 def test_gray_1080p_properties(ctx):
     """Full BASELINE size: constant frames -> constant gray (truncation of 255*Y), any ratio."""
     import torch

@@ -50,6 +50,39 @@ def test_warp_exact_mode_matches_oracle(ctx, oracle, case):
     assert np.array_equal(mask.cpu().numpy(), ref_mask)
 
 
+STRESS = ["horizon", "flip", "minify", "magnify", "quarter_turn"]
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("kind", STRESS)
+def test_warp_stress_matrices_match_oracle(ctx, oracle, kind, interp):
+    """Maps whose inverse leaves the comfortable range: W == 0 and sign changes (INT clamp, short saturation), mirrored
+    and rotated sources, 40x minification and 100x magnification (every 1/32-px phase of one source pixel)."""
+    n, sh, sw, dh, dw = 3, 45, 73, 51, 80
+    frames = synth_frames(n, sh, sw, seed=11)
+    mats = make_matrices(n, sw, sh, kind).astype(np.float32)
+    ref, ref_mask, ref_cnt = oracle.warp_clip(frames, mats, (dw, dh), interp=interp, border=BORDER)
+    dst, mask, cnt = ctx.warp_batch(frames, mats, (dw, dh), interp=interp, border=BORDER, subpix="q5", want_mask=True, want_count=True)
+    assert np.array_equal(dst.cpu().numpy(), ref, equal_nan=True)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
+    if interp == "bilinear" and kind != "horizon":
+        ref, ref_mask, _ = oracle.warp_clip(frames, mats, (dw, dh), interp="bilinear", border=BORDER, subpix="exact")
+        dst, mask, _ = ctx.warp_batch(frames, mats, (dw, dh), interp="bilinear", border=BORDER, subpix="exact")
+        assert np.array_equal(dst.cpu().numpy(), ref, equal_nan=True)
+        assert np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+@pytest.mark.parametrize("kind", ["horizon", "flip", "magnify"])
+def test_blur_stress_matrices_match_oracle(ctx, oracle, kind):
+    frames = synth_frames(3, 45, 73, seed=13)
+    mats = make_matrices(3, 73, 45, kind)
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (73, 45), 0.7, 5, interp="bilinear", border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (73, 45), 0.7, 5, interp="bilinear", border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref, equal_nan=True)
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
 def test_warp_masks_zero_path(ctx, oracle):
     frames = synth_frames(2, 45, 73, seed=3)
     mats = make_matrices(2, 73, 45, "similarity").astype(np.float32)

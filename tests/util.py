@@ -43,6 +43,21 @@ def test_matrices(n, w, h, kind, seed=1):
             m[2, 1] = rng.uniform(-2e-4, 2e-4)
         elif kind == "far":
             m = similarity(3.0 * w, -2.0 * h, 0.1, 1.0)
+        elif kind == "horizon":
+            # the projective denominator of the inverse map changes sign inside the output: W == 0 columns, coordinates
+            # beyond the INT clamp and the short saturation of cv::warpPerspective
+            m = similarity(rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-0.02, 0.02), 1.0, w / 2, h / 2)
+            m[2, 0] = (-1.0 if i % 2 else 1.0) * 2.0 / w
+            m[2, 1] = rng.uniform(-1e-3, 1e-3)
+        elif kind == "flip":
+            m = similarity(rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-0.03, 0.03), 1.0, w / 2, h / 2)
+            m = m @ np.array([[-1.0, 0, w - 1.0], [0, 1, 0], [0, 0, 1]])
+        elif kind == "minify":
+            m = similarity(w * 0.45, h * 0.45, rng.uniform(-0.2, 0.2), 0.02 + 0.03 * i)
+        elif kind == "magnify":
+            m = similarity(rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-0.3, 0.3), 37.0 + 100.0 * i, w / 2, h / 2)
+        elif kind == "quarter_turn":
+            m = similarity(0.0, 0.0, np.pi / 2 + rng.uniform(-1e-3, 1e-3), 1.0, w / 2, h / 2)
         else:
             raise ValueError(kind)
         mats.append(m)

@@ -7,9 +7,11 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
 OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
+# small groups (a six-counter pass once sat until its timeout on this pool); a failed pass ends the script: no further
+# GPU step after a timeout
+for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_dis_$i -- python3 $R/tools/pmc_target.py > $OUT/pass$i.log 2>&1 || echo "pass failed: $grp"
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_dis_$i -- python3 $R/tools/pmc_target.py > $OUT/pass$i.log 2>&1 || { echo "pass failed: $grp"; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

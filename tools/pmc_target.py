@@ -1,5 +1,5 @@
 """Workload for the PMC passes of tools/pmc_dis.sh: two Flow passes (C2, 256 x 1080p) and one Motion Apply pass
-(C3 kind: bicubic, blur 0.5, 17 samples, 64 x 1080p) so that level_kernel, pis2_kernel and the blur warp kernel
+(C3 kind: bicubic, blur 0.5, 17 samples, 64 x 1080p) so that level_kernel, pis4_kernel and the blur warp kernel
 each appear a few times.  Run directly under rocprofv3 (`-- python3 tools/pmc_target.py`)."""
 import json, sys
 from pathlib import Path
