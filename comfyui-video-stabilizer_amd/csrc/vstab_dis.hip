@@ -141,6 +141,64 @@ __global__ __launch_bounds__(256) void area_u8_kernel(const uint8_t* __restrict_
     }
 }
 
+// General ratio with the tap tables in LDS: one workgroup per (frame, AREA_ROWS output rows) forms the column table once
+// and one row table per output row (area_axis is fp64 with three divisions: per output pixel, as in mode 2 above, it
+// made the three small pyramid levels of a 1080p clip cost more than the 4x4 level that reads sixteen times the bytes).
+// Same taps, same f32 sums in the same order as mode 2.
+constexpr int AREA_ROWS = 32, AREA_MAX_COLS = 1024;
+struct AreaTaps { int n, first; float a[8]; };   // the taps of an output sample are consecutive source samples
+
+// area_axis without the indexed tap arrays (which live in scratch memory): a leading partial sample, full samples, a
+// trailing partial one.  The host admits ratios below 6, so the k < 7 / k < 8 guards of area_axis never cut a run short.
+__device__ __forceinline__ void area_taps(int d, int ssize, double scale, AreaTaps& t)
+{
+    const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+    const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = d_ceil(fsx1), sx2 = d_floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    const int lead = (sx1 - fsx1 > 1e-3) ? 1 : 0;
+    const int k_end = lead + (sx2 - sx1);
+    const bool tail = fsx2 - sx2 > 1e-3;
+    double at = fsx2 - sx2;
+    at = at < 1. ? at : 1.;
+    at = at < cell ? at : cell;
+    const float a_lead = (float)((sx1 - fsx1) / cell), a_full = (float)(1.0 / cell), a_tail = (float)(at / cell);
+    t.n = k_end + (tail ? 1 : 0);
+    t.first = sx1 - lead;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t.a[k] = (k < lead) ? a_lead : (k < k_end) ? a_full : (k == k_end && tail) ? a_tail : 0.f;
+}
+
+__global__ __launch_bounds__(256) void area_general_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n, int sh,
+                                                                int sw, int dh, int dw, double scale_x, double scale_y)
+{
+    __shared__ AreaTaps s_x[AREA_MAX_COLS];
+    __shared__ AreaTaps s_y[AREA_ROWS];
+    const int groups = (dh + AREA_ROWS - 1) / AREA_ROWS;
+    const int f = (int)blockIdx.x / groups, y0 = ((int)blockIdx.x % groups) * AREA_ROWS;
+    const int rows = min(AREA_ROWS, dh - y0);
+    for (int x = threadIdx.x; x < dw; x += blockDim.x) area_taps(x, sw, scale_x, s_x[x]);
+    if ((int)threadIdx.x < rows) area_taps(y0 + (int)threadIdx.x, sh, scale_y, s_y[threadIdx.x]);
+    __syncthreads();
+    const uint8_t* S = src + (size_t)f * sh * sw;
+    uint8_t* D = dst + ((size_t)f * dh + y0) * dw;
+    for (int t = threadIdx.x; t < rows * dw; t += blockDim.x) {
+        const int ry = t / dw, x = t - ry * dw;
+        const AreaTaps& ax = s_x[x];
+        const AreaTaps& ay = s_y[ry];
+        float sum = 0.f;
+        for (int j = 0; j < ay.n; j++) {
+            const uint8_t* row = S + (size_t)(ay.first + j) * sw + ax.first;
+            float buf = 0.f;
+            for (int k = 0; k < ax.n; k++) buf += row[k] * ax.a[k];
+            const float term = ay.a[j] * buf;
+            sum = (j == 0) ? term : sum + term;
+        }
+        D[t] = (uint8_t)sat_u8_round(sum);
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_replicate_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n, int h, int w)
 {
     const int we = w + 2 * DIS_BORDER, he = h + 2 * DIS_BORDER;
@@ -213,13 +271,26 @@ __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ 
         const int k = (int)(r / n);
         const float* a = aux + k * aplane + (size_t)f * h * ws + j;
         float* o = out + k * oplane + (size_t)f * hs * ws + j;
+        // the last PSZ rows stay in registers (the row that leaves the window is not read twice), and the PSZ loads of a
+        // chunk are independent of the running sum: same additions in the same order
+        float ring[PSZ];
         float sum = 0.f;
-        for (int i = 0; i < PSZ; i++) sum += a[(size_t)i * ws];
+#pragma unroll
+        for (int i = 0; i < PSZ; i++) { ring[i] = a[(size_t)i * ws]; sum += ring[i]; }
         o[0] = sum;
         int is = 1;
-        for (int i = PSZ; i < h; i++) {
-            sum += (a[(size_t)i * ws] - a[(size_t)(i - PSZ) * ws]);
-            if ((i - PSZ + 1) % PSTR == 0) { o[(size_t)is * ws] = sum; is++; }
+        for (int i0 = PSZ; i0 < h; i0 += PSZ) {
+            float v[PSZ];
+#pragma unroll
+            for (int k = 0; k < PSZ; k++) v[k] = (i0 + k < h) ? a[(size_t)(i0 + k) * ws] : 0.f;
+#pragma unroll
+            for (int k = 0; k < PSZ; k++) {
+                if (i0 + k < h) {
+                    sum += (v[k] - ring[k]);
+                    ring[k] = v[k];
+                    if ((k + 1) % PSTR == 0) { o[(size_t)is * ws] = sum; is++; }   // (i - PSZ + 1) % PSTR == 0 for i = i0 + k, i0 a multiple of PSZ
+                }
+            }
         }
     }
 }
@@ -1041,7 +1112,11 @@ int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh,
     int mode = fast ? ((isx == 2 && isy == 2) ? 0 : 1) : 2;
     if (mode == 1 && isx == 4 && isy == 4 && sw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) mode = 3;
     const long long items = (long long)n * dh * dw;
-    hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for(items)), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
+    const long long row_groups = (long long)n * ((dh + AREA_ROWS - 1) / AREA_ROWS);
+    if (mode == 2 && dw <= AREA_MAX_COLS && row_groups < 0x7fffffffLL)
+        hipLaunchKernelGGL(area_general_rows_kernel, dim3((unsigned)row_groups), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, scale_x, scale_y);
+    else
+        hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for(items)), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }
