@@ -167,9 +167,14 @@ class _DIS:
         return vo.dis_flow_stateful(i0, i1, self.params)
 
 
+DIS_DISABLED = None   # a message: DISOpticalFlow.create raises it (drives the reference's flow.py:90-107 fallback selection)
+
+
 class DISOpticalFlow:
     @staticmethod
     def create(preset=DISOPTICAL_FLOW_PRESET_FAST):
+        if DIS_DISABLED:
+            raise RuntimeError(DIS_DISABLED)
         return _DIS(preset)
 
 

@@ -123,9 +123,10 @@ def main() -> None:
     from nodes import motion_apply as ma  # noqa: E402
     from nodes import motion_meta as mm  # noqa: E402
     from nodes import stabilizer_utils as su  # noqa: E402
+    from nodes import video_stabilizer_classic as vc  # noqa: E402
     from nodes import video_stabilizer_flow as vf  # noqa: E402
 
-    assert vf.cv2 is cv2_standin and su.cv2 is cv2_standin and ma.cv2 is cv2_standin
+    assert vf.cv2 is cv2_standin and su.cv2 is cv2_standin and ma.cv2 is cv2_standin and vc.cv2 is cv2_standin
     OUT.mkdir(exist_ok=True)
     index = {"flow": [], "apply": [], "note": "reference control flow over oracle primitives; see make_e2e_golden.py"}
 
@@ -176,22 +177,43 @@ def main() -> None:
         # sticky mode downgrade
         ("broken_sticky_similarity", "broken", 4, ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)),
         ("broken_sticky_perspective", "broken", 4, ("expand", "perspective", False, 1.0, 0.0, 0.6, (0, 0, 0), 16.0)),
+        # the Classic node's pipeline (nodes/video_stabilizer_classic.py:163-568: GFTT + pyramidal LK per
+        # pair, its own fallback order and meta keys) -- "estimator": "classic"
+        ("classic_mid_crop_and_pad_similarity", "mid", 1, ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0), "classic"),
+        ("classic_persp_expand_perspective", "persp", 4, ("expand", "perspective", False, 0.9, 0.3, 0.6, (16, 32, 64), 24.0), "classic"),
+        ("classic_shake_crop_translation", "shake", 2, ("crop", "translation", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0), "classic"),
+        ("classic_tiny_too_few_corners", "tiny", 1, ("crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0), "classic"),
+        # the Flow node on its fallback estimator (flow.py:90-130: DIS cannot be created, cv2.optflow is
+        # missing -> phase correlation, every pair reported as "translation") -- "estimator": "flow_phase_correlate"
+        ("phase_shake_expand_similarity", "shake", 2, ("expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0), "flow_phase_correlate"),
+        ("phase_mid_crop_and_pad_translation", "mid", 1, ("crop_and_pad", "translation", False, 1.0, 0.2, 0.6, (127, 127, 127), 30.0), "flow_phase_correlate"),
     ]
     results = {}
-    for name, clip, stride, args in flow_cases:
+    for case in flow_cases:
+        name, clip, stride, args = case[:4]
+        estimator = case[4] if len(case) > 4 else "flow"
         PROGRESS.clear()
         cv2_standin.CALLS.clear()
         frames = clip_frames(clip)
         ctx = su._normalize_video_input(frames)
-        res = vf._stabilize_frames(ctx, *args)
+        if estimator == "classic":
+            res = vc._stabilize_frames(ctx, *args)
+        elif estimator == "flow_phase_correlate":
+            cv2_standin.DIS_DISABLED = "disabled by VSTAB_FLOW_BACKEND"   # the text this build's fallback reason quotes
+            try:
+                res = vf._stabilize_frames(ctx, *args)
+            finally:
+                cv2_standin.DIS_DISABLED = None
+        else:
+            res = vf._stabilize_frames(ctx, *args)
         out_frames = np.asarray(res.frames, dtype=np.float32)
         out_masks = np.asarray(res.masks, dtype=np.float32)
         meta = jsonable(res.meta)
         results[name] = (frames, res.meta)
         np.savez_compressed(OUT / f"flow_{name}.npz", frames=out_frames[:, ::stride, ::stride], masks=out_masks[:, ::stride, ::stride])
         (OUT / f"flow_{name}.json").write_text(json.dumps({
-            "clip": clip, "args": jsonable(list(args)), "stride": stride, "out_shape": list(out_frames.shape), "meta": meta,
-            "progress": jsonable(PROGRESS), "cv2_calls": dict(cv2_standin.CALLS)}))
+            "clip": clip, "args": jsonable(list(args)), "estimator": estimator, "stride": stride, "out_shape": list(out_frames.shape),
+            "meta": meta, "progress": jsonable(PROGRESS), "cv2_calls": dict(cv2_standin.CALLS)}))
         index["flow"].append(name)
         modes = [t["mode"] for t in meta.get("estimated_motion", {}).get("per_transition", [])]
         print(f"flow  {name}: out {out_frames.shape} modes {sorted(set(modes))} applied {meta.get('transform_mode_applied')}"

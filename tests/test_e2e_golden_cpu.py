@@ -81,10 +81,26 @@ def test_host_planning_reproduces_reference_meta(pkg, oracle, name):
     frames = clip_frames(spec["clip"])
     n, h, w, _ = frames.shape
     gray = oracle.gray_for_estimation(frames, hm._working_estimation_size(w, h))
-    flow = oracle.dis_flow_clip(gray)
-    records = [oracle.fit_all_modes(flow[i], 8, mode)[0] for i in range(n - 1)]
+    estimator = spec.get("estimator", "flow")
+    if estimator == "classic":      # classic.py:69-160: corners of frame i tracked into frame i+1, fits on the tracked pairs
+        records = []
+        for i in range(n - 1):
+            feats = oracle.good_features(gray[i], **oracle.GFTT)
+            if feats.shape[0] < 12:
+                records.append({})
+                continue
+            nxt, status = oracle.lk_track(gray[i], gray[i + 1], feats, **oracle.LK)
+            records.append(oracle.fit_all_modes_points(feats, nxt, status, mode)[0])
+    elif estimator == "flow_phase_correlate":   # flow.py:110-130: a translation per pair, confidence = peak response
+        records = []
+        for tx, ty, resp in oracle.phase_correlate_clip(gray):
+            m = np.array([[1.0, 0.0, tx], [0.0, 1.0, ty], [0.0, 0.0, 1.0]], np.float32)
+            records.append({"translation": {"matrix": m, "confidence": float(resp), "residual": 0.0, "accepted": True}})
+    else:
+        flow = oracle.dis_flow_clip(gray)
+        records = [oracle.fit_all_modes(flow[i], 8, mode)[0] for i in range(n - 1)]
     plan = fp.plan_stabilization(OraclePlanCtx(oracle), records, (w, h), n, framing, mode, lock, strength, smooth, keep_fov,
-                                 tuple(rgb), float(max(1.0, fps)), float(fps))
+                                 tuple(rgb), float(max(1.0, fps)), float(fps), estimator=estimator)
     meta = fp.prepare_meta(plan)
     # the padding statistics need the warp; everything else of flow.py:596-640 is host work
     for key in ("padding_fraction_mean", "padding_fraction_max"):

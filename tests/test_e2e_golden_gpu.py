@@ -1,6 +1,8 @@
 """The package's nodes against fixtures produced by the REFERENCE's own pipelines (tests/golden/make_e2e_golden.py:
 `_stabilize_frames` of nodes/video_stabilizer_flow.py:213-640 and `apply_motion` of nodes/motion_apply.py:297-429 run
-unmodified in the build container, their cv2 calls answered by the CPU oracle).
+unmodified in the build container, their cv2 calls answered by the CPU oracle; likewise the Classic node's
+`_stabilize_frames`, nodes/video_stabilizer_classic.py:163-568, and the Flow node on its phase-correlation fallback,
+flow.py:90-130 -- the fixture's "estimator" field says which).
 
 What this pins: the whole host chain of this build -- sticky mode walk (flow.py:324-346), working-size rescale, path /
 target / diffs (flow.py:356-371), the crop_and_pad recentre incl. safe_region_* / center_offset (flow.py:500-529),
@@ -103,7 +105,13 @@ def test_flow_node_matches_reference_pipeline(api, ctx, monkeypatch, name):
 
     monkeypatch.setattr(api.fp, "ProgressBar", Bar)
     a = spec["args"]
-    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), a[0], a[1], a[2], a[3], a[4], a[5], tuple(a[6]), a[7])
+    # "classic": the Classic node's estimator (classic.py:69-160); "flow_phase_correlate": the Flow node with DIS
+    # unavailable (flow.py:90-130), which this build selects through VSTAB_FLOW_BACKEND
+    estimator = spec.get("estimator", "flow")
+    if estimator == "flow_phase_correlate":
+        monkeypatch.setenv("VSTAB_FLOW_BACKEND", "phase_correlate")
+    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), a[0], a[1], a[2], a[3], a[4], a[5], tuple(a[6]), a[7],
+                                   estimator="classic" if estimator == "classic" else "flow")
     got_meta = json.loads(json.dumps(res.meta))
     perspective = a[1] == "perspective"
     assert_meta_close(got_meta, want_meta, mat_tol=2e-5 if perspective else 2e-6)
@@ -117,7 +125,7 @@ def test_flow_node_matches_reference_pipeline(api, ctx, monkeypatch, name):
     assert list(got_frames.shape) == spec["out_shape"] and got_masks.shape == got_frames.shape[:3] + (1,)
     same = (np.array([e["applied_matrix"] for e in got_meta["stabilization_warp"]["per_frame"]]).tobytes()
             == np.array([e["applied_matrix"] for e in want_meta["stabilization_warp"]["per_frame"]]).tobytes())
-    if a[1] == "translation" or "bypass" in name:
+    if (a[1] == "translation" and estimator == "flow") or "bypass" in name:
         assert same, "translation mode: the applied matrices must be bit-equal to the reference's"
     assert_pixels(got_frames[:, ::stride, ::stride], want_frames, same, f"{name}.frames")
     assert_pixels(got_masks[:, ::stride, ::stride], want_masks, same, f"{name}.masks")
