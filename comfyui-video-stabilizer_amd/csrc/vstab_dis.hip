@@ -1190,16 +1190,40 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     layout(carver);
 
     // ---- per-frame preparation: pyramid, padded copies, gradients, structure tensor ----
+    // The pyramid is a chain (each level is the INTER_AREA of the previous one) and stays on the call's stream.  The
+    // rest of a level's preparation is only needed when the coarse-to-fine chain reaches that level, and the chain's
+    // coarse levels are latency-bound launches that leave most of the chip idle: it runs on a second stream, coarsest
+    // level first, one event per level (VSTAB_DIS_PREP_STREAM=0 keeps everything on one stream: A/B measurement).
+    static const bool two_streams = [] { const char* e = getenv("VSTAB_DIS_PREP_STREAM"); return !(e && atoi(e) == 0); }();
+    static_assert(sizeof(ctx->ev_prep) / sizeof(ctx->ev_prep[0]) >= MAX_LEVELS, "one event per pyramid level");
+    hipStream_t ps = st;
+    if (two_streams) {
+        if (!ctx->prep_stream) {
+            VSTAB_HIP(hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+            VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_pyramid, hipEventDisableTiming));
+            for (auto& ev : ctx->ev_prep) VSTAB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        ps = ctx->prep_stream;
+    }
     for (int i = FINEST; i <= coarsest; i++) {
         const LevelGeom& g = G[i];
         if (i == FINEST) { if (launch_area(st, gray, I[i], n, h, w, g.h, g.w)) return 1; }
         else { if (launch_area(st, I[i - 1], I[i], n, G[i - 1].h, G[i - 1].w, g.h, g.w)) return 1; }
+    }
+    if (two_streams) {
+        // (the event also orders the second stream behind every earlier kernel of this stream that still reads the workspace)
+        VSTAB_HIP(hipEventRecord(ctx->ev_pyramid, st));
+        VSTAB_HIP(hipStreamWaitEvent(ps, ctx->ev_pyramid, 0));
+    }
+    for (int i = coarsest; i >= FINEST; i--) {
+        const LevelGeom& g = G[i];
         const long long px = (long long)n * g.h * g.w;
-        hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)n * (g.h + 32) * (g.w + 32))), dim3(256), 0, st, I[i], Iext[i], n, g.h, g.w);
-        hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(px)), dim3(256), 0, st, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h * g.ws)), dim3(256), 0, st, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
-        hipLaunchKernelGGL(tensor_v_kernel, dim3(grid_for(5LL * n * g.ws, 64)), dim3(64), 0, st, aux, tensor[i], n, g.h, g.ws, g.hs);
+        hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)n * (g.h + 32) * (g.w + 32))), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
+        hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(px)), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
+        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h * g.ws)), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(tensor_v_kernel, dim3(grid_for(5LL * n * g.ws, 64)), dim3(64), 0, ps, aux, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
+        if (two_streams) VSTAB_HIP(hipEventRecord(ctx->ev_prep[i], ps));
     }
     VSTAB_HIP(hipMemsetAsync(Ul[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
     VSTAB_HIP(hipMemsetAsync(Vl[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
@@ -1217,6 +1241,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.spin_limit = 1 << 22;
         if (const char* e = getenv("VSTAB_DEBUG_PIS_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // tests: 0 forces the timeout report
         pa.status = ctx->d_status;
+        if (two_streams) VSTAB_HIP(hipStreamWaitEvent(st, ctx->ev_prep[i], 0));   // this level's padded image, gradients, tensor
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
         // one wavefront per stripe walks its rows in groups of four; two share the groups where a stripe has more rows

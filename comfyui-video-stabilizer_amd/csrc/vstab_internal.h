@@ -67,6 +67,11 @@ struct vstab_ctx {
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_xfer_sync = nullptr;
     hipStream_t xfer_stream = nullptr;
+    // DIS: the per-level image preparation (pad, gradients, structure tensor) runs on its own stream beside the
+    // coarse-to-fine chain, one event per pyramid level (vstab_dis.hip)
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_prep[16] = {};   // MAX_LEVELS of vstab_dis.hip
+    hipEvent_t ev_pyramid = nullptr;
 };
 
 enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired
