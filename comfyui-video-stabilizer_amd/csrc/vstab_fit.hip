@@ -17,7 +17,16 @@
 
 namespace {
 
-constexpr int FIT_THREADS = 256;
+// One block per pair.  Every pass over the ~8 k samples is a loop of dependent loads (index map -> sample); with 256
+// threads a SIMD held one wavefront and nothing hid that latency (0.21 ms per clip); 512 or 1024 threads: 0.16 ms
+// (tools/fit_phases.py: validity scan 32 us, RANSAC +32, least squares + residual +43, the two medians +44; what is
+// left is the ~60 workgroup barriers between short passes and the single-lane sections).
+#ifndef VSTAB_FIT_THREADS
+#define VSTAB_FIT_THREADS 1024
+#endif
+constexpr int FIT_THREADS = VSTAB_FIT_THREADS;
+constexpr int FIT_WAVES = FIT_THREADS / 64;
+static_assert(FIT_THREADS >= 256 && FIT_THREADS % 64 == 0 && FIT_THREADS <= 1024, "radix_select uses 256 histogram bins");
 constexpr int RANSAC_BATCH = 16;   // typical clips converge in < 10 iterations; 16 keeps the scoring loop in registers
 constexpr int MAX_SORT = 16384;
 
@@ -42,14 +51,16 @@ __device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int
 }
 
 template <typename T>
-__device__ __forceinline__ T block_sum(T v, T* scratch /* >= 4 */)
+__device__ __forceinline__ T block_sum(T v, T* scratch /* >= FIT_WAVES */)
 {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    const T total = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    T total = scratch[0];
+#pragma unroll
+    for (int i = 1; i < FIT_WAVES; i++) total += scratch[i];
     __syncthreads();
     return total;
 }
@@ -103,7 +114,7 @@ __device__ unsigned radix_select(const unsigned* keys, int n, int r, int* hist /
 {
     unsigned prefix = 0, mask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[threadIdx.x] = 0;   // FIT_THREADS == 256 bins
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;   // 256 bins
         __syncthreads();
         for (int k = threadIdx.x; k < n; k += FIT_THREADS) {
             const unsigned key = keys[k];
@@ -139,14 +150,14 @@ __device__ unsigned radix_select(const unsigned* keys, int n, int r, int* hist /
 __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
 {
     __shared__ unsigned s_sort[MAX_SORT];
-    __shared__ int s_hist[FIT_THREADS];
+    __shared__ int s_hist[256];
     __shared__ int s_sel[2];
     __shared__ double s_model[RANSAC_BATCH][6];
     __shared__ float s_modelf[RANSAC_BATCH][6];
     __shared__ int s_idx[RANSAC_BATCH][2];
     __shared__ int s_cnt[RANSAC_BATCH];
-    __shared__ double s_red[8];
-    __shared__ int s_redi[8];
+    __shared__ double s_red[FIT_WAVES];
+    __shared__ int s_redi[FIT_WAVES];
     __shared__ int s_scan[FIT_THREADS];
     __shared__ double s_best[6];
     __shared__ int s_ctl[4];   // 0: done flag, 1: niters, 2: iter, 3: maxGood
@@ -168,15 +179,22 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
         load_point(F, a.gw, a.step, g, px, py, cx, cy);
         local += (isfinite(cx) && isfinite(cy)) ? 1 : 0;
     }
-    s_scan[tid] = local;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < FIT_THREADS; i++) { const int v = s_scan[i]; s_scan[i] = acc; acc += v; }
-        s_redi[0] = acc;
+    {   // exclusive prefix sum of `local` over the block: wavefront scan, then the wavefront totals
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += o;
+        }
+        if ((tid & 63) == 63) s_redi[tid >> 6] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int i = 0; i < (tid >> 6); i++) before += s_redi[i];
+        s_scan[tid] = before + incl - local;
+        if (tid == FIT_THREADS - 1) s_sel[0] = before + incl;
     }
     __syncthreads();
-    const int nv = s_redi[0];
+    const int nv = s_sel[0];
     {
         int o = s_scan[tid];
         for (int g = g0; g < g1; g++) {
@@ -367,9 +385,9 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
                 }
                 if ((tid & 63) == 0) { s_redi[tid >> 6] = less; s_hist[tid >> 6] = (int)below; }
                 __syncthreads();
-                const int total_less = s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
-                unsigned mx = (unsigned)s_hist[0];
-                for (int i = 1; i < 4; i++) mx = (unsigned)s_hist[i] > mx ? (unsigned)s_hist[i] : mx;
+                int total_less = 0;
+                unsigned mx = 0;
+                for (int i = 0; i < FIT_WAVES; i++) { total_less += s_redi[i]; mx = (unsigned)s_hist[i] > mx ? (unsigned)s_hist[i] : mx; }
                 const unsigned lo = total_less == mid ? mx : hi;
                 med[axis] = (key_value(lo) + key_value(hi)) / 2.0f;
             }
