@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_
 // ---- per-pixel phase bodies (shared by every launch shape) -----------------------------------
 // All indices below are GLOBAL element indices into the [P][h][w] planes; (x, y) is the pixel.
 struct VrBufs {
-    float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *A11, *A12, *A22, *b1, *b2, *wgt, *tU, *tV, *dU, *dV;
+    float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *tU, *tV, *dU, *dV;   // (the linear system's coefficients live in registers)
 };
 
 __device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ sx,
@@ -1177,8 +1177,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         aux = c.take<float>(5 * (size_t)n * F.h * F.ws);
         Sx = c.take<float>((size_t)P * F.hs * F.ws);
         Sy = c.take<float>((size_t)P * F.hs * F.ws);
-        float** planes[] = {&vb.avg, &vb.Iz, &vb.Ix, &vb.Iy, &vb.Ixx, &vb.Ixy, &vb.Iyy, &vb.Ixz, &vb.Iyz, &vb.A11,
-                            &vb.A12, &vb.A22, &vb.b1, &vb.b2, &vb.wgt, &vb.tU, &vb.tV, &vb.dU, &vb.dV};
+        float** planes[] = {&vb.avg, &vb.Iz, &vb.Ix, &vb.Iy, &vb.Ixx, &vb.Ixy, &vb.Iyy, &vb.Ixz, &vb.Iyz, &vb.tU, &vb.tV, &vb.dU, &vb.dV};
         for (float** pl : planes) *pl = c.take<float>(npF);
     };
     {
