@@ -30,6 +30,13 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.vstab_abi_version() == 1
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md shows a reference maintainer what each C entry point replaces: none may be missing from it."""
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    missing = [name for name in header_symbols() if name not in doc]
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
+
+
 def test_product_fails_loudly_without_gpu(pkg):
     import torch
 
