@@ -18,7 +18,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_LIB_PATH = _HERE / "_build" / "libvstab_oracle.so"
+# VSTAB_ORACLE_LIB: another build of the checker (the sanitizer build of `make -C oracle sanitize`, tools/oracle_sanitize.sh)
+_LIB_PATH = Path(os.environ["VSTAB_ORACLE_LIB"]).resolve() if os.environ.get("VSTAB_ORACLE_LIB") else _HERE / "_build" / "libvstab_oracle.so"
 
 INTERP = {"bilinear": 0, "bicubic": 1}
 SUBPIX = {"q5": 0, "exact": 1}
