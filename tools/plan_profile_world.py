@@ -11,7 +11,7 @@ ctx = native.Context(0)
 n, h, w = 256, 1080, 1920
 frames = bench.synth_clip(n, 0, h, w, torch.device("cuda", 0))
 table = fp.estimate_transitions(ctx, frames, hm._working_estimation_size(w, h), "similarity")
-total = 2048
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 big = np.concatenate([table] * 9)[: total - 1]
 args = (ctx, big, (w, h), total, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0, 16.0)
 for _ in range(10):
