@@ -151,7 +151,7 @@ def _gray(ctx, device_frames, working_size, peaks_out):
     if peaks_out is None:
         return ctx.gray_downscale(device_frames, working_size)
     gray, peaks = ctx.gray_downscale(device_frames, working_size, want_range=True)
-    peaks_out.append(peaks)
+    peaks_out.append(hm.prefetch_peaks(peaks))
     return gray
 
 

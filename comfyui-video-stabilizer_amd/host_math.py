@@ -142,7 +142,14 @@ def apply_value_range(batch, peaks, ctx=None):
     Returns (batch -- a rescaled copy if anything changed, else the same tensor --, value_range of frame 0).
     A device batch is rescaled by the library (vstab_apply_value_range: IEEE float32 division like numpy's; a torch
     division on the GPU need not round the same way), a host batch with NumPy."""
-    big = peaks.cpu() > 1.5   # one small D2H copy; the comparison runs on the host (no extra kernel launch in the step)
+    # the comparison runs on the host (no extra kernel launch in the step); peaks that were prefetched to the host
+    # behind the pass that produced them (prefetch_peaks) cost no copy here
+    host = getattr(peaks, "_vstab_host", None)
+    if host is not None:
+        host[1].synchronize()
+        big = host[0] > 1.5
+    else:
+        big = peaks.cpu() > 1.5
     if bool(big.any()):
         if batch.device.type == "cpu":
             out = batch.clone()
@@ -155,6 +162,21 @@ def apply_value_range(batch, peaks, ctx=None):
 
             batch = (ctx or native.default_context()).apply_value_range(batch, peaks)
     return batch, ("0_255" if bool(big[0]) else "0_1")
+
+
+def prefetch_peaks(peaks):
+    """Start the device -> host copy of a per-frame maxima tensor on the current stream, into page-locked memory, right
+    behind the kernel that fills it; apply_value_range then finds the values on the host (the stream has long passed
+    the copy by the time the estimation's own synchronisation returns) instead of paying a blocking copy of its own
+    between the estimation and the warp, where the GPU idles."""
+    if peaks.device.type == "cpu":
+        return peaks
+    host = torch.empty(peaks.shape, dtype=peaks.dtype, pin_memory=True)
+    host.copy_(peaks, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    peaks._vstab_host = (host, done)
+    return peaks
 
 
 def resolve_value_range(context: "VideoContext", peaks=None, ctx=None) -> bool:
