@@ -19,10 +19,12 @@ namespace {
 
 // One block per pair.  Every pass over the ~8 k samples is a loop of dependent loads (index map -> sample); with 256
 // threads a SIMD held one wavefront and nothing hid that latency (0.21 ms per clip); 512 or 1024 threads: 0.16 ms
+// (512 is the default: at 1024 the 128-register cap spills 560 B per thread into scratch -- 238 MB of HBM writes per
+// launch in the PMC view -- for no gain)
 // (tools/fit_phases.py: validity scan 32 us, RANSAC +32, least squares + residual +43, the two medians +44; what is
 // left is the ~60 workgroup barriers between short passes and the single-lane sections).
 #ifndef VSTAB_FIT_THREADS
-#define VSTAB_FIT_THREADS 1024
+#define VSTAB_FIT_THREADS 512
 #endif
 constexpr int FIT_THREADS = VSTAB_FIT_THREADS;
 constexpr int FIT_WAVES = FIT_THREADS / 64;
