@@ -844,6 +844,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef float f2_t __attribute__((ext_vector_type(2)));
     f4_t* lP = reinterpret_cast<f4_t*>(vr_lds);
+    // Plane reads of the tile stages: a uniform plane base (SGPR pair) + a 32-bit BYTE offset per lane selects the
+    // `global_load_dword v, v_off, s[base]` form; indexing the float pointer instead makes the compiler widen the element
+    // index to 64 bits first (one v_lshl_add_u64 per load: 36 of them in the linear-system stage).  A pair's plane has
+    // fewer than 2^30 pixels (pyramid level of a <= 960-px working image; checked by the host).
+#define LDF(P, idx) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (unsigned)(idx) * 4u))
     // increment ping-pong: (dU,dV) <-> (tU,tV) planes of the workspace
     float* dIn_u = b.dU + base;  float* dIn_v = b.dV + base;
     float* dOut_u = b.tU + base; float* dOut_v = b.tV + base;
@@ -873,12 +878,12 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                 if (lx >= 0 && lx < lw && ly >= 0 && ly < lh) {
                     const int gx = ox + lx, gy = oy + ly;
                     const int q = gy * w + gx;
-                    du = dIn_u[q]; dv = dIn_v[q];
+                    du = LDF(dIn_u, q); dv = LDF(dIn_v, q);
                     const int qr = (gx + 1 < w) ? q + 1 : q;
                     const int qd = (gy + 1 < h) ? q + w : q;
-                    const float tu = U[q] + du, tv = V[q] + dv;
-                    const float tur = U[qr] + dIn_u[qr], tvr = V[qr] + dIn_v[qr];
-                    const float tud = U[qd] + dIn_u[qd], tvd = V[qd] + dIn_v[qd];
+                    const float tu = LDF(U, q) + du, tv = LDF(V, q) + dv;
+                    const float tur = LDF(U, qr) + LDF(dIn_u, qr), tvr = LDF(V, qr) + LDF(dIn_v, qr);
+                    const float tud = LDF(U, qd) + LDF(dIn_u, qd), tvd = LDF(V, qd) + LDF(dIn_v, qd);
                     const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
                     wv = div_plain(a.alpha2, __builtin_sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
                 }
@@ -910,9 +915,8 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             const int gx = ox + lx;
                             const int q = gy * w + gx;
                             const int li = (ly + 1) * pw + lx + 1;
-                            const unsigned uq_ = (unsigned)q;   // uniform (SGPR) plane base + 32-bit lane offset
-                            const float Ix = pIx[uq_], Iy = pIy[uq_], Iz = pIz[uq_], Ixx = pIxx[uq_], Ixy = pIxy[uq_], Iyy = pIyy[uq_],
-                                        Ixz = pIxz[uq_], Iyz = pIyz[uq_];
+                            const float Ix = LDF(pIx, q), Iy = LDF(pIy, q), Iz = LDF(pIz, q), Ixx = LDF(pIxx, q), Ixy = LDF(pIxy, q),
+                                        Iyy = LDF(pIyy, q), Ixz = LDF(pIxz, q), Iyz = LDF(pIyz, q);
                             const f4_t own = lP[li];
                             const float du = own.x, dv = own.y;
                             float a11, a12, a22, B1, B2;
@@ -946,11 +950,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             // smoothness term, accumulated in OpenCV's red/black scatter order.  `color` IS the global
                             // checkerboard parity (gx + gy) & 1 of the pixel, so the order is known at compile time.
                             const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
-                            const float wq = own.z, uq = U[q], vq = V[q];
-#define SM_RIGHT() if (has_r) { B1 += wq * (U[q + 1] - uq); a11 += wq; B2 += wq * (V[q + 1] - vq); a22 += wq; }
-#define SM_LEFT()  if (has_l) { const float wl = lP[li - 1].z; B1 -= wl * (uq - U[q - 1]); a11 += wl; B2 -= wl * (vq - V[q - 1]); a22 += wl; }
-#define SM_DOWN()  if (has_d) { B1 += wq * (U[q + w] - uq); a11 += wq; B2 += wq * (V[q + w] - vq); a22 += wq; }
-#define SM_UP()    if (has_u) { const float wu = lP[li - pw].z; B1 -= wu * (uq - U[q - w]); a11 += wu; B2 -= wu * (vq - V[q - w]); a22 += wu; }
+                            const float wq = own.z, uq = LDF(U, q), vq = LDF(V, q);
+#define SM_RIGHT() if (has_r) { B1 += wq * (LDF(U, q + 1) - uq); a11 += wq; B2 += wq * (LDF(V, q + 1) - vq); a22 += wq; }
+#define SM_LEFT()  if (has_l) { const float wl = lP[li - 1].z; B1 -= wl * (uq - LDF(U, q - 1)); a11 += wl; B2 -= wl * (vq - LDF(V, q - 1)); a22 += wl; }
+#define SM_DOWN()  if (has_d) { B1 += wq * (LDF(U, q + w) - uq); a11 += wq; B2 += wq * (LDF(V, q + w) - vq); a22 += wq; }
+#define SM_UP()    if (has_u) { const float wu = lP[li - pw].z; B1 -= wu * (uq - LDF(U, q - w)); a11 += wu; B2 -= wu * (vq - LDF(V, q - w)); a22 += wu; }
                             if (color == 0) { SM_RIGHT() SM_LEFT() SM_DOWN() SM_UP() }
                             else            { SM_LEFT() SM_RIGHT() SM_UP() SM_DOWN() }
 #undef SM_RIGHT
@@ -1034,6 +1038,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
         if (FUSED) __syncthreads();
     }
 #undef FOR_PX
+#undef LDF
     FUSED_MARK(7);
     if ((FUSED || MODE == LEVEL_UPSAMPLE) && a.nextU != nullptr) {
         const int nn = a.nh * a.nw;
