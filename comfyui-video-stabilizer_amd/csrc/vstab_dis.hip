@@ -595,8 +595,15 @@ struct VrBufs {
     float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *tU, *tV, *dU, *dV;   // (the linear system's coefficients live in registers)
 };
 
+// Plane accesses of the per-pixel phases: every pointer below is the PAIR's plane (a uniform base, SGPR pair) and every
+// index a 32-bit in-plane index, turned into a 32-bit byte offset -- the `global_load_dword v, v_off, s[base]` form, with
+// no 64-bit address arithmetic per access (a level of a <= 960-px working image has far fewer than 2^30 pixels).
+__device__ __forceinline__ float ldf(const float* p, int i) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (unsigned)i * 4u); }
+__device__ __forceinline__ void stf(float* p, int i, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + (unsigned)i * 4u) = v; }
+__device__ __forceinline__ float ldb(const uint8_t* p, int i) { return (float)p[(unsigned)i]; }
+
 __device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ sx,
-                                           const float* __restrict__ sy, float* __restrict__ U, float* __restrict__ V, long long t, int i,
+                                           const float* __restrict__ sy, float* __restrict__ U, float* __restrict__ V, int q, int i,
                                            int j, int h, int w, int ws, int hs)
 {
     int end_is = i / PSTR < hs - 1 ? i / PSTR : hs - 1;
@@ -605,35 +612,36 @@ __device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const
     int end_js = j / PSTR < ws - 1 ? j / PSTR : ws - 1;
     int start_js = j - PSZ >= 0 ? (j - PSZ) / PSTR + 1 : 0;
     if (start_js > end_js) start_js = end_js;
-    const float i0 = (float)I0[(size_t)i * w + j];
+    const float i0 = ldb(I0, i * w + j);
     float sum_coef = 0.f, sum_Ux = 0.f, sum_Uy = 0.f;
     for (int is = start_is; is <= end_is; is++)
         for (int js = start_js; js <= end_js; js++) {
-            const float sxv = sx[(size_t)is * ws + js], syv = sy[(size_t)is * ws + js];
+            const float sxv = ldf(sx, is * ws + js), syv = ldf(sy, is * ws + js);
             float j_m = (float)j + sxv, i_m = (float)i + syv;
             j_m = j_m > 0.0f ? j_m : 0.0f;
             j_m = j_m < (float)w - 1.0f - DIS_EPS ? j_m : (float)w - 1.0f - DIS_EPS;
             i_m = i_m > 0.0f ? i_m : 0.0f;
             i_m = i_m < (float)h - 1.0f - DIS_EPS ? i_m : (float)h - 1.0f - DIS_EPS;
             const int j_l = (int)j_m, j_u = j_l + 1, i_l = (int)i_m, i_u = i_l + 1;
-            const float diff = (j_m - j_l) * (i_m - i_l) * I1[(size_t)i_u * w + j_u] +
-                               (j_u - j_m) * (i_m - i_l) * I1[(size_t)i_u * w + j_l] +
-                               (j_m - j_l) * (i_u - i_m) * I1[(size_t)i_l * w + j_u] +
-                               (j_u - j_m) * (i_u - i_m) * I1[(size_t)i_l * w + j_l] - i0;
+            const float diff = (j_m - j_l) * (i_m - i_l) * ldb(I1, i_u * w + j_u) +
+                               (j_u - j_m) * (i_m - i_l) * ldb(I1, i_u * w + j_l) +
+                               (j_m - j_l) * (i_u - i_m) * ldb(I1, i_l * w + j_u) +
+                               (j_u - j_m) * (i_u - i_m) * ldb(I1, i_l * w + j_l) - i0;
             const float ad = __builtin_fabsf(diff);
             const float coef = 1 / (ad > 1.0f ? ad : 1.0f);
             sum_Ux += coef * sxv;
             sum_Uy += coef * syv;
             sum_coef += coef;
         }
-    U[t] = sum_Ux / sum_coef;
-    V[t] = sum_Uy / sum_coef;
+    stf(U, q, sum_Ux / sum_coef);
+    stf(V, q, sum_Uy / sum_coef);
 }
 
+// b: the pair's planes (VrBufs shifted to the pair, see level_kernel)
 __device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ U,
-                                           const float* __restrict__ V, const VrBufs& b, long long t, int x, int y, int h, int w)
+                                           const float* __restrict__ V, const VrBufs& b, int q, int x, int y, int h, int w)
 {
-    const float u = U[t], v = V[t];
+    const float u = ldf(U, q), v = ldf(V, q);
     const float mx = x + u, my = y + v;
     const int sx = (int)__builtin_rintf(mx * 32.f), sy = (int)__builtin_rintf(my * 32.f);
     const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
@@ -641,37 +649,35 @@ __device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const
     const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1, wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
     const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
     const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
-    const float v00 = (float)I1[(size_t)y0 * w + x0], v01 = (float)I1[(size_t)y0 * w + x1];
-    const float v10 = (float)I1[(size_t)y1 * w + x0], v11 = (float)I1[(size_t)y1 * w + x1];
+    const float v00 = ldb(I1, y0 * w + x0), v01 = ldb(I1, y0 * w + x1);
+    const float v10 = ldb(I1, y1 * w + x0), v11 = ldb(I1, y1 * w + x1);
     const float warped = v00 * (wy0 * wx0) + v01 * (wy0 * wx1) + v10 * (wy1 * wx0) + v11 * (wy1 * wx1);
-    const float i0 = (float)I0[(size_t)y * w + x];
-    b.avg[t] = i0 * 0.5f + warped * 0.5f + 0.f;
-    b.Iz[t] = warped - i0;
-    b.tU[t] = u;
-    b.tV[t] = v;
-    b.dU[t] = 0.f;
-    b.dV[t] = 0.f;
+    const float i0 = ldb(I0, q);
+    stf(b.avg, q, i0 * 0.5f + warped * 0.5f + 0.f);
+    stf(b.Iz, q, warped - i0);
+    stf(b.tU, q, u);
+    stf(b.tV, q, v);
+    stf(b.dU, q, 0.f);
+    stf(b.dV, q, 0.f);
 }
 
-__device__ __forceinline__ void vr_deriv1_px(const VrBufs& b, long long t, int x, int y, int h, int w)
+__device__ __forceinline__ void vr_deriv1_px(const VrBufs& b, int q, int x, int y, int h, int w)
 {
-    const long long base = t - (long long)y * w - x;
-    const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
-    const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
-    b.Ix[t] = b.avg[xr] - b.avg[xl];
-    b.Iy[t] = b.avg[yd] - b.avg[yu];
-    b.Ixz[t] = b.Iz[xr] - b.Iz[xl];
-    b.Iyz[t] = b.Iz[yd] - b.Iz[yu];
+    const int xl = y * w + clampi(x - 1, 0, w - 1), xr = y * w + clampi(x + 1, 0, w - 1);
+    const int yu = clampi(y - 1, 0, h - 1) * w + x, yd = clampi(y + 1, 0, h - 1) * w + x;
+    stf(b.Ix, q, ldf(b.avg, xr) - ldf(b.avg, xl));
+    stf(b.Iy, q, ldf(b.avg, yd) - ldf(b.avg, yu));
+    stf(b.Ixz, q, ldf(b.Iz, xr) - ldf(b.Iz, xl));
+    stf(b.Iyz, q, ldf(b.Iz, yd) - ldf(b.Iz, yu));
 }
 
-__device__ __forceinline__ void vr_deriv2_px(const VrBufs& b, long long t, int x, int y, int h, int w)
+__device__ __forceinline__ void vr_deriv2_px(const VrBufs& b, int q, int x, int y, int h, int w)
 {
-    const long long base = t - (long long)y * w - x;
-    const long long xl = base + (long long)y * w + clampi(x - 1, 0, w - 1), xr = base + (long long)y * w + clampi(x + 1, 0, w - 1);
-    const long long yu = base + (long long)clampi(y - 1, 0, h - 1) * w + x, yd = base + (long long)clampi(y + 1, 0, h - 1) * w + x;
-    b.Ixx[t] = b.Ix[xr] - b.Ix[xl];
-    b.Ixy[t] = b.Ix[yd] - b.Ix[yu];
-    b.Iyy[t] = b.Iy[yd] - b.Iy[yu];
+    const int xl = y * w + clampi(x - 1, 0, w - 1), xr = y * w + clampi(x + 1, 0, w - 1);
+    const int yu = clampi(y - 1, 0, h - 1) * w + x, yd = clampi(y + 1, 0, h - 1) * w + x;
+    stf(b.Ixx, q, ldf(b.Ix, xr) - ldf(b.Ix, xl));
+    stf(b.Ixy, q, ldf(b.Ix, yd) - ldf(b.Ix, yu));
+    stf(b.Iyy, q, ldf(b.Iy, yd) - ldf(b.Iy, yu));
 }
 
 // ---- bilinear f32 resize (flow upsampling between levels), result scaled by `mul` ------------
@@ -685,9 +691,10 @@ __device__ __forceinline__ void lin_coord(int d, double scale, int ssize, int& s
 }
 
 __device__ __forceinline__ void upsample_px(const float* __restrict__ sU, const float* __restrict__ sV, float* __restrict__ dU,
-                                            float* __restrict__ dV, long long src_base, long long t, int dx, int dy, int sh, int sw,
+                                            float* __restrict__ dV, int q, int dx, int dy, int sh, int sw,
                                             double scale_x, double scale_y, float mul)
 {
+    // sU / sV: the pair's source level, dU / dV: the pair's destination level (uniform bases), q: destination pixel
     int sx, sy;
     float fx, fy;
     lin_coord(dx, scale_x, sw, sx, fx);
@@ -697,14 +704,11 @@ __device__ __forceinline__ void upsample_px(const float* __restrict__ sU, const 
     const int sy0 = clampi(sy, 0, sh - 1), sy1 = clampi(sy + 1, 0, sh - 1);
     const int sx1 = sx + 1 < sw ? sx + 1 : sx;
     const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-    const float* S0 = sU + src_base + (long long)sy0 * sw;
-    const float* S1 = sU + src_base + (long long)sy1 * sw;
-    float r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
-    dU[t] = (r0 * b0 + r1 * b1) * mul;
-    S0 = sV + src_base + (long long)sy0 * sw;
-    S1 = sV + src_base + (long long)sy1 * sw;
-    r0 = S0[sx] * a0 + S0[sx1] * a1; r1 = S1[sx] * a0 + S1[sx1] * a1;
-    dV[t] = (r0 * b0 + r1 * b1) * mul;
+    const int r0i = sy0 * sw, r1i = sy1 * sw;
+    float r0 = ldf(sU, r0i + sx) * a0 + ldf(sU, r0i + sx1) * a1, r1 = ldf(sU, r1i + sx) * a0 + ldf(sU, r1i + sx1) * a1;
+    stf(dU, q, (r0 * b0 + r1 * b1) * mul);
+    r0 = ldf(sV, r0i + sx) * a0 + ldf(sV, r0i + sx1) * a1; r1 = ldf(sV, r1i + sx) * a0 + ldf(sV, r1i + sx1) * a1;
+    stf(dV, q, (r0 * b0 + r1 * b1) * mul);
 }
 
 #ifdef VSTAB_FUSED_TRACE   // developer build: per-phase time of one workgroup (tools/fused_phases.py)
@@ -809,33 +813,41 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     const uint8_t* I1 = a.I + (size_t)(pair + 1) * npx;
     const float* sx = a.Sx + (size_t)pair * a.hs * a.ws;
     const float* sy = a.Sy + (size_t)pair * a.hs * a.ws;
-    const VrBufs& b = a.vb;
-    const float* __restrict__ U = a.U + base;
-    const float* __restrict__ V = a.V + base;
+    // every plane shifted to this pair once (uniform: scalar registers); all accesses below are 32-bit in-plane offsets
+    VrBufs b = a.vb;
+    {
+        float** planes[] = {&b.avg, &b.Iz, &b.Ix, &b.Iy, &b.Ixx, &b.Ixy, &b.Iyy, &b.Ixz, &b.Iyz, &b.tU, &b.tV, &b.dU, &b.dV};
+#pragma unroll
+        for (float** pl : planes) *pl += base;
+    }
+    float* __restrict__ Uw = a.U + base;   // the pair's flow at this level (densify writes it, the merge updates it)
+    float* __restrict__ Vw = a.V + base;
+    const float* __restrict__ U = Uw;
+    const float* __restrict__ V = Vw;
     // the pixels of this workgroup: all of the pair's (fused), or every nparts-th block of FUSED_T (split)
 #define FOR_PX(...)                                                                                   \
     for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {   \
         const int y = q_ / w, x = q_ - y * w;                                                         \
-        const long long t = base + q_;                                                                \
+        const int t = q_;                                                                             \
         (void)x; (void)y;                                                                             \
         __VA_ARGS__;                                                                                  \
     }                                                                                                 \
     if (FUSED) __syncthreads();
     if (FUSED || MODE == LEVEL_PRE) {
         // (a thread densifies and warps the SAME pixels, and the warp reads U,V of its own pixel only)
-        FOR_PX(densify_px(I0, I1, sx, sy, a.U, a.V, t, y, x, h, w, a.ws, a.hs))
+        FOR_PX(densify_px(I0, I1, sx, sy, Uw, Vw, t, y, x, h, w, a.ws, a.hs))
         FUSED_MARK(0);
-        FOR_PX(vr_warp_px(I0, I1, a.U, a.V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
+        FOR_PX(vr_warp_px(I0, I1, U, V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
         FUSED_MARK(1);
     }
     if (FUSED || MODE == LEVEL_DERIV1) { FOR_PX(vr_deriv1_px(b, t, x, y, h, w)) }
     if (FUSED || MODE == LEVEL_DERIV2) { FOR_PX(vr_deriv2_px(b, t, x, y, h, w)) }
     FUSED_MARK(2);
 
-    const float* __restrict__ pIx = b.Ix + base;   const float* __restrict__ pIy = b.Iy + base;
-    const float* __restrict__ pIz = b.Iz + base;   const float* __restrict__ pIxx = b.Ixx + base;
-    const float* __restrict__ pIxy = b.Ixy + base; const float* __restrict__ pIyy = b.Iyy + base;
-    const float* __restrict__ pIxz = b.Ixz + base; const float* __restrict__ pIyz = b.Iyz + base;
+    const float* __restrict__ pIx = b.Ix;   const float* __restrict__ pIy = b.Iy;
+    const float* __restrict__ pIz = b.Iz;   const float* __restrict__ pIxx = b.Ixx;
+    const float* __restrict__ pIxy = b.Ixy; const float* __restrict__ pIyy = b.Iyy;
+    const float* __restrict__ pIxz = b.Ixz; const float* __restrict__ pIyz = b.Iyz;
     // LDS tile: one float4 (dU, dV, smoothness weight, pad) per padded pixel -- an update reads its own and its
     // left / up neighbours' triples with one 16-B load each and the right / down increments with one 8-B load each
     // (6 LDS instructions instead of 15), and only three loop-invariant addresses per owned pixel are live in the
@@ -850,8 +862,8 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     // fewer than 2^30 pixels (pyramid level of a <= 960-px working image; checked by the host).
 #define LDF(P, idx) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (unsigned)(idx) * 4u))
     // increment ping-pong: (dU,dV) <-> (tU,tV) planes of the workspace
-    float* dIn_u = b.dU + base;  float* dIn_v = b.dV + base;
-    float* dOut_u = b.tU + base; float* dOut_v = b.tV + base;
+    float* dIn_u = b.dU;  float* dIn_v = b.dV;
+    float* dOut_u = b.tU; float* dOut_v = b.tV;
 
     // split: one (iteration, tile) per workgroup; the increment ping-pong is a function of the iteration's parity
     const int it_lo = FUSED ? 0 : a.it, it_hi = FUSED ? VAR_ITERS : a.it + 1;
@@ -1029,11 +1041,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
         tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
     }
     // mergeCheckerboard(W, tempW): W + dW of the last fixed-point iteration
-    if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) { dIn_u = b.tU + base; dIn_v = b.tV + base; }   // where iteration VAR_ITERS-1 wrote
+    if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) { dIn_u = b.tU; dIn_v = b.tV; }   // where iteration VAR_ITERS-1 wrote
     if (FUSED || MODE == LEVEL_MERGE) {
         for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {
-            a.U[base + q_] = U[q_] + dIn_u[q_];
-            a.V[base + q_] = V[q_] + dIn_v[q_];
+            stf(Uw, q_, ldf(U, q_) + ldf(dIn_u, q_));
+            stf(Vw, q_, ldf(V, q_) + ldf(dIn_v, q_));
         }
         if (FUSED) __syncthreads();
     }
@@ -1042,10 +1054,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     FUSED_MARK(7);
     if ((FUSED || MODE == LEVEL_UPSAMPLE) && a.nextU != nullptr) {
         const int nn = a.nh * a.nw;
-        const long long nbase = (long long)pair * nn;
+        float* __restrict__ nU = a.nextU + (long long)pair * nn;
+        float* __restrict__ nV = a.nextV + (long long)pair * nn;
         for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < nn; q_ += nparts * (int)blockDim.x) {
             const int dy = q_ / a.nw, dx = q_ - dy * a.nw;
-            upsample_px(a.U, a.V, a.nextU, a.nextV, base, nbase + q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
+            upsample_px(U, V, nU, nV, q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
         }
     }
 #ifdef VSTAB_FUSED_TRACE
