@@ -49,8 +49,11 @@ unsigned grid_for(long long items, int block = 256)
     return (unsigned)b;
 }
 
-#define GRID_STRIDE(t, total) \
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (total); t += (long long)gridDim.x * blockDim.x)
+// The per-frame preparation kernels run on a (blocks, frames) grid: blockIdx.y is the frame (or pair) and the element
+// index inside it is 32-bit, so that splitting it into (row, column) is one 32-bit division instead of two 64-bit
+// divisions of a clip-wide index (which cost more than the work of these kernels).
+#define FRAME_STRIDE(t, per_frame) \
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned)(per_frame); t += gridDim.x * blockDim.x)
 
 __device__ __forceinline__ int d_ceil(double v) { int i = (int)v; return i + (i < v); }
 __device__ __forceinline__ int d_floor(double v) { int i = (int)v; return i - (i > v); }
@@ -100,13 +103,11 @@ __global__ __launch_bounds__(256) void area_u8_kernel(const uint8_t* __restrict_
                                                       int sw, int dh, int dw, int mode, int kx, int ky, double scale_x,
                                                       double scale_y)
 {
-    const long long total = (long long)n * dh * dw;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % dw);
-        const long long r = t / dw;
-        const int y = (int)(r % dh);
-        const int f = (int)(r / dh);
-        const uint8_t* S = src + (size_t)f * sh * sw;
+    const int f = blockIdx.y;
+    const uint8_t* S = src + (size_t)f * sh * sw;
+    uint8_t* D = dst + (size_t)f * dh * dw;
+    FRAME_STRIDE(t, dh * dw) {
+        const int y = (int)(t / (unsigned)dw), x = (int)(t - (unsigned)y * (unsigned)dw);
         int o;
         if (mode == 0) {
             const uint8_t* s0 = S + (size_t)(2 * y) * sw + 2 * x;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void area_u8_kernel(const uint8_t* __restrict_
             }
             o = sat_u8_round(sum);
         }
-        dst[t] = (uint8_t)o;
+        D[t] = (uint8_t)o;
     }
 }
 
@@ -202,34 +203,32 @@ __global__ __launch_bounds__(256) void area_general_rows_kernel(const uint8_t* _
 __global__ __launch_bounds__(256) void pad_replicate_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n, int h, int w)
 {
     const int we = w + 2 * DIS_BORDER, he = h + 2 * DIS_BORDER;
-    const long long total = (long long)n * he * we;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % we);
-        const long long r = t / we;
-        const int y = (int)(r % he);
-        const int f = (int)(r / he);
+    const int f = blockIdx.y;
+    const uint8_t* S = src + (size_t)f * h * w;
+    uint8_t* D = dst + (size_t)f * he * we;
+    FRAME_STRIDE(t, he * we) {
+        const int y = (int)(t / (unsigned)we), x = (int)(t - (unsigned)y * (unsigned)we);
         const int sx = clampi(x - DIS_BORDER, 0, w - 1), sy = clampi(y - DIS_BORDER, 0, h - 1);
-        dst[t] = src[((size_t)f * h + sy) * w + sx];
+        D[t] = S[(unsigned)(sy * w + sx)];
     }
 }
 
 __global__ __launch_bounds__(256) void sobel_kernel(const uint8_t* __restrict__ I, short* __restrict__ Ix, short* __restrict__ Iy, int n, int h, int w)
 {
-    const long long total = (long long)n * h * w;
-    GRID_STRIDE(t, total) {
-        const int x = (int)(t % w);
-        const long long r = t / w;
-        const int y = (int)(r % h);
-        const int f = (int)(r / h);
-        const uint8_t* S = I + (size_t)f * h * w;
-        const uint8_t* r0 = S + (size_t)reflect101(y - 1, h) * w;
-        const uint8_t* r1 = S + (size_t)y * w;
-        const uint8_t* r2 = S + (size_t)reflect101(y + 1, h) * w;
+    const int f = blockIdx.y;
+    const uint8_t* S = I + (size_t)f * h * w;
+    short* Dx = Ix + (size_t)f * h * w;
+    short* Dy = Iy + (size_t)f * h * w;
+    FRAME_STRIDE(t, h * w) {
+        const int y = (int)(t / (unsigned)w), x = (int)(t - (unsigned)y * (unsigned)w);
+        const uint8_t* r0 = S + (unsigned)(reflect101(y - 1, h) * w);
+        const uint8_t* r1 = S + (unsigned)(y * w);
+        const uint8_t* r2 = S + (unsigned)(reflect101(y + 1, h) * w);
         const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
         const int gx = (r0[xr] + 2 * r1[xr] + r2[xr]) - (r0[xl] + 2 * r1[xl] + r2[xl]);
         const int gy = (r2[xl] + 2 * r2[x] + r2[xr]) - (r0[xl] + 2 * r0[x] + r0[xr]);
-        Ix[t] = (short)gx;
-        Iy[t] = (short)gy;
+        Dx[t] = (short)gx;
+        Dy[t] = (short)gy;
     }
 }
 
@@ -241,20 +240,22 @@ __global__ __launch_bounds__(256) void sobel_kernel(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void tensor_h_kernel(const short* __restrict__ Ix, const short* __restrict__ Iy, float* __restrict__ aux,
                                                        int n, int h, int w, int ws)
 {
-    const long long total = (long long)n * h * ws;
     const size_t plane = (size_t)n * h * ws;
-    GRID_STRIDE(t, total) {
-        const int js = (int)(t % ws);
-        const long long row = t / ws;
-        const short* xr = Ix + (size_t)row * w + js * PSTR;
-        const short* yr = Iy + (size_t)row * w + js * PSTR;
+    const int f = blockIdx.y;
+    const short* Fx = Ix + (size_t)f * h * w;
+    const short* Fy = Iy + (size_t)f * h * w;
+    float* A = aux + (size_t)f * h * ws;
+    FRAME_STRIDE(t, h * ws) {
+        const int row = (int)(t / (unsigned)ws), js = (int)(t - (unsigned)row * (unsigned)ws);
+        const short* xr = Fx + (unsigned)(row * w + js * PSTR);
+        const short* yr = Fy + (unsigned)(row * w + js * PSTR);
         int s_xx = 0, s_yy = 0, s_xy = 0, s_x = 0, s_y = 0;
 #pragma unroll
         for (int j = 0; j < PSZ; j++) {
             const int gx = xr[j], gy = yr[j];
             s_xx += gx * gx; s_yy += gy * gy; s_xy += gx * gy; s_x += gx; s_y += gy;
         }
-        float* o = aux + t;
+        float* o = A + t;
         o[0] = (float)s_xx; o[plane] = (float)s_yy; o[2 * plane] = (float)s_xy; o[3 * plane] = (float)s_x; o[4 * plane] = (float)s_y;
     }
 }
@@ -262,13 +263,10 @@ __global__ __launch_bounds__(256) void tensor_h_kernel(const short* __restrict__
 // vertical running sums: one thread per (quantity, frame, js)
 __global__ __launch_bounds__(64) void tensor_v_kernel(const float* __restrict__ aux, float* __restrict__ out, int n, int h, int ws, int hs)
 {
-    const long long cols = 5LL * n * ws;
+    // grid (column blocks, frames, 5 quantities): no index arithmetic beyond the column
     const size_t aplane = (size_t)n * h * ws, oplane = (size_t)n * hs * ws;
-    GRID_STRIDE(t, cols) {
-        const int j = (int)(t % ws);
-        const long long r = t / ws;
-        const int f = (int)(r % n);
-        const int k = (int)(r / n);
+    const int f = blockIdx.y, k = blockIdx.z;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ws; j += gridDim.x * blockDim.x) {
         const float* a = aux + k * aplane + (size_t)f * h * ws + j;
         float* o = out + k * oplane + (size_t)f * hs * ws + j;
         // the last PSZ rows stay in registers (the row that leaves the window is not read twice), and the PSZ loads of a
@@ -1073,12 +1071,10 @@ __global__ __launch_bounds__(256) void final_sample_kernel(const float* __restri
                                                            int P, int sh, int sw, int gh, int gw, int step, double scale_x, double scale_y,
                                                            float mul)
 {
-    const long long total = (long long)P * gh * gw;
-    GRID_STRIDE(t, total) {
-        const int gx = (int)(t % gw);
-        const long long rr = t / gw;
-        const int gy = (int)(rr % gh);
-        const long long p = rr / gh;
+    const long long p = blockIdx.y;
+    out += (size_t)p * gh * gw * 2;
+    FRAME_STRIDE(t, gh * gw) {
+        const int gy = (int)(t / (unsigned)gw), gx = (int)(t - (unsigned)gy * (unsigned)gw);
         const int dx = gx * step, dy = gy * step;
         int sx, sy;
         float fx, fy;
@@ -1129,12 +1125,11 @@ int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh,
     VSTAB_REQUIRE(scale_x >= 1.0 && scale_y >= 1.0 && scale_x < 6.0 && scale_y < 6.0, "dis: area ratio %.3fx%.3f unsupported", scale_x, scale_y);
     int mode = fast ? ((isx == 2 && isy == 2) ? 0 : 1) : 2;
     if (mode == 1 && isx == 4 && isy == 4 && sw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) mode = 3;
-    const long long items = (long long)n * dh * dw;
     const long long row_groups = (long long)n * ((dh + AREA_ROWS - 1) / AREA_ROWS);
     if (mode == 2 && dw <= AREA_MAX_COLS && row_groups < 0x7fffffffLL)
         hipLaunchKernelGGL(area_general_rows_kernel, dim3((unsigned)row_groups), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, scale_x, scale_y);
     else
-        hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for(items)), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
+        hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for((long long)dh * dw), (unsigned)n), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }
@@ -1159,6 +1154,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
 {
     hipStream_t st = ctx->stream;
     const int P = n - 1;
+    VSTAB_REQUIRE(n <= 65535, "vstab_dis_flow_batch: %d frames in one call (the frame index is a grid dimension: at most 65535)", n);
     LevelGeom G[MAX_LEVELS];
     {
         int fraction = 1, ch = 0, cw = 0;
@@ -1234,11 +1230,10 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     }
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
-        const long long px = (long long)n * g.h * g.w;
-        hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)n * (g.h + 32) * (g.w + 32))), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
-        hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(px)), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)n * g.h * g.ws)), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
-        hipLaunchKernelGGL(tensor_v_kernel, dim3(grid_for(5LL * n * g.ws, 64)), dim3(64), 0, ps, aux, tensor[i], n, g.h, g.ws, g.hs);
+        hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)(g.h + 32) * (g.w + 32)), (unsigned)n), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
+        hipLaunchKernelGGL(sobel_kernel, dim3(grid_for((long long)g.h * g.w), (unsigned)n), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
+        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)g.h * g.ws), (unsigned)n), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(tensor_v_kernel, dim3((unsigned)((g.ws + 63) / 64), (unsigned)n, 5u), dim3(64), 0, ps, aux, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
         if (two_streams) VSTAB_HIP(hipEventRecord(ctx->ev_prep[i], ps));
     }
@@ -1340,11 +1335,11 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     const float mul = (float)(1 << FINEST);
     if (grid_flow) {
         const int gh = (h + sample_step - 1) / sample_step, gw = (w + sample_step - 1) / sample_step;
-        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)P * gh * gw)), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], grid_flow, P,
+        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)gh * gw), (unsigned)P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], grid_flow, P,
                            F.h, F.w, gh, gw, sample_step, fsx, fsy, mul);
     }
     if (flow) {
-        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)P * h * w)), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], flow, P, F.h, F.w,
+        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)h * w), (unsigned)P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], flow, P, F.h, F.w,
                            h, w, 1, fsx, fsy, mul);
     }
     VSTAB_HIP(hipGetLastError());
