@@ -9,7 +9,7 @@ box, AND over frames, 3x3 erode) is one libvstab call for the whole clip (`Conte
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Sequence, Tuple
 
 import numpy as np
 
