@@ -35,6 +35,8 @@ def run_smoke(repo_root: str) -> None:
     from oracle import oracle as vo  # checker only
 
     from . import native
+
+    native.load_library()   # the HIP extension must be there: no CPU fallback exists
     from .nodes import VideoStabilizerFlow, VideoStabilizerMotionApply
 
     assert torch.cuda.is_available(), "smoke() needs cuda:0"
