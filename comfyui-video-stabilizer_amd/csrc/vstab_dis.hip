@@ -920,6 +920,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             const int half_lw = (lw + 1) >> 1;
             const int ncol = lh * half_lw;
             float c11[2][SOR_NPT], c12[2][SOR_NPT], c22[2][SOR_NPT], cb1[2][SOR_NPT], cb2[2][SOR_NPT];
+            float cy22[2][SOR_NPT];   // refined reciprocal of c22 (that of c11 rides in the LDS tile's spare float)
             int cidx[2][SOR_NPT];
             // Owned pixel j = 2*u + colour of this thread: k = threadIdx.x + u * FUSED_T = ly * half_lw + xh, advanced
             // incrementally (one division per tile).  The loop is NOT unrolled: one pixel's ~60 temporaries are live at a
@@ -986,13 +987,18 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
 #undef SM_LEFT
 #undef SM_DOWN
 #undef SM_UP
+                            // The two SOR denominators of a pixel are fixed for the ten half-sweeps: their refined reciprocals
+                            // are formed once here (3 instructions each) instead of in each of the pixel's five updates.
+                            const float y11 = rcp_refined(a11), y22 = rcp_refined(a22);
 #pragma unroll
                             for (int jj = 0; jj < 2 * SOR_NPT; jj++)
                                 if (jj == j) {
                                     cidx[jj & 1][jj >> 1] = li;
                                     c11[jj & 1][jj >> 1] = a11; c12[jj & 1][jj >> 1] = a12; c22[jj & 1][jj >> 1] = a22;
                                     cb1[jj & 1][jj >> 1] = B1; cb2[jj & 1][jj >> 1] = B2;
+                                    cy22[jj & 1][jj >> 1] = y22;
                                 }
+                            lP[li].w = y11;   // own pixel's spare slot: nobody else reads or writes this dword
                         }
                 }
                 if (color == 1) {
@@ -1022,13 +1028,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             const float sigmaV = wl * pl.y + wq * pr.y + wu * pu.y + wq * pd.y;
                             float du = pc.x, dv = pc.y;
                             // the two divisions in the split form of `/` (rcp_refined + div_shared, above): denominators >= zeta^2, so
-                            // v_div_scale / v_div_fixup are the identity; 8 instead of 11 instructions each.  The empty asm keeps
-                            // the reciprocal inside the loop: hoisted out of the ten half-sweeps it needs 20 more registers
-                            // and spills (profiles/r02_dis_launch_forms.md)
-                            float d11 = c11[color][u], d22 = c22[color][u];
-                            asm volatile("" : "+v"(d11), "+v"(d22));
-                            du += a.omega * (div_shared(sigmaU + cb1[color][u] - dv * c12[color][u], d11, rcp_refined(d11)) - du);
-                            dv += a.omega * (div_shared(sigmaV + cb2[color][u] - du * c12[color][u], d22, rcp_refined(d22)) - dv);
+                            // v_div_scale / v_div_fixup are the identity.  The refined reciprocals come from stage 2: the one of
+                            // c11 in the tile's spare float (it arrives with `pc`), the one of c22 in a register (ten registers
+                            // fit since the plane accesses stopped using 64-bit addresses; twenty did not: round-2 profile notes)
+                            du += a.omega * (div_shared(sigmaU + cb1[color][u] - dv * c12[color][u], c11[color][u], pc.w) - du);
+                            dv += a.omega * (div_shared(sigmaV + cb2[color][u] - du * c12[color][u], c22[color][u], cy22[color][u]) - dv);
                             *reinterpret_cast<f2_t*>(lP + li) = f2_t{du, dv};
                         }
                         __builtin_amdgcn_sched_barrier(0);   // keep the owned pixels' updates apart (register pressure)
