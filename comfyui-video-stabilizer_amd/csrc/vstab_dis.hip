@@ -49,6 +49,18 @@ unsigned grid_for(long long items, int block = 256)
     return (unsigned)b;
 }
 
+// blocks along x of a (blocks, frames) grid: enough to cover a frame, but no more than keeps the whole grid near
+// 8192 workgroups (a thread then strides over a few elements instead of the launch paying for tens of thousands of
+// one-element workgroups)
+dim3 frame_grid(long long per_frame, int frames, int block = 256)
+{
+    long long b = (per_frame + block - 1) / block;
+    const long long cap = std::max(1LL, (256LL * 32) / std::max(frames, 1));
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b, (unsigned)frames);
+}
+
 // The per-frame preparation kernels run on a (blocks, frames) grid: blockIdx.y is the frame (or pair) and the element
 // index inside it is 32-bit, so that splitting it into (row, column) is one 32-bit division instead of two 64-bit
 // divisions of a clip-wide index (which cost more than the work of these kernels).
@@ -1148,7 +1160,7 @@ int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh,
     if (mode == 2 && dw <= AREA_MAX_COLS && row_groups < 0x7fffffffLL)
         hipLaunchKernelGGL(area_general_rows_kernel, dim3((unsigned)row_groups), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, scale_x, scale_y);
     else
-        hipLaunchKernelGGL(area_u8_kernel, dim3(grid_for((long long)dh * dw), (unsigned)n), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
+        hipLaunchKernelGGL(area_u8_kernel, frame_grid((long long)dh * dw, n), dim3(256), 0, st, src, dst, n, sh, sw, dh, dw, mode, isx, isy, scale_x, scale_y);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }
@@ -1249,9 +1261,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     }
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
-        hipLaunchKernelGGL(pad_replicate_kernel, dim3(grid_for((long long)(g.h + 32) * (g.w + 32)), (unsigned)n), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
-        hipLaunchKernelGGL(sobel_kernel, dim3(grid_for((long long)g.h * g.w), (unsigned)n), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, dim3(grid_for((long long)g.h * g.ws), (unsigned)n), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(pad_replicate_kernel, frame_grid((long long)(g.h + 32) * (g.w + 32), n), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
+        hipLaunchKernelGGL(sobel_kernel, frame_grid((long long)g.h * g.w, n), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
+        hipLaunchKernelGGL(tensor_h_kernel, frame_grid((long long)g.h * g.ws, n), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
         hipLaunchKernelGGL(tensor_v_kernel, dim3((unsigned)((g.ws + 63) / 64), (unsigned)n, 5u), dim3(64), 0, ps, aux, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
         if (two_streams) VSTAB_HIP(hipEventRecord(ctx->ev_prep[i], ps));
@@ -1354,11 +1366,11 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     const float mul = (float)(1 << FINEST);
     if (grid_flow) {
         const int gh = (h + sample_step - 1) / sample_step, gw = (w + sample_step - 1) / sample_step;
-        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)gh * gw), (unsigned)P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], grid_flow, P,
+        hipLaunchKernelGGL(final_sample_kernel, frame_grid((long long)gh * gw, P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], grid_flow, P,
                            F.h, F.w, gh, gw, sample_step, fsx, fsy, mul);
     }
     if (flow) {
-        hipLaunchKernelGGL(final_sample_kernel, dim3(grid_for((long long)h * w), (unsigned)P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], flow, P, F.h, F.w,
+        hipLaunchKernelGGL(final_sample_kernel, frame_grid((long long)h * w, P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], flow, P, F.h, F.w,
                            h, w, 1, fsx, fsy, mul);
     }
     VSTAB_HIP(hipGetLastError());
