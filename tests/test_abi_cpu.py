@@ -37,6 +37,53 @@ def test_integration_doc_names_every_entry_point():
     assert not missing, f"INTEGRATION.md does not mention {missing}"
 
 
+def header_prototypes():
+    """(name, [parameter type strings]) of every `int vstab_*(...)` prototype in include/vstab.h."""
+    text = re.sub(r"/\*.*?\*/", " ", (ROOT / "include" / "vstab.h").read_text(), flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = []
+    for m in re.finditer(r"\bint\s+(vstab_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        params = [p.strip() for p in m.group(2).replace("\n", " ").split(",")]
+        out.append((m.group(1), [] if params == ["void"] else params))
+    return out
+
+
+def test_null_context_is_rejected_before_any_gpu_work(pkg):
+    """Every entry point that takes a context refuses a NULL one with a non-zero status and a message -- checked without a
+    GPU: the argument check comes before the first HIP call (all other arguments are zeros / NULL too)."""
+    from vstab_amd import native
+
+    lib = ctypes.CDLL(str(native.LIB_PATH))
+    lib.vstab_last_error.restype = ctypes.c_char_p
+    checked = 0
+    for name, params in header_prototypes():
+        if not params or not params[0].startswith("vstab_ctx*"):
+            continue
+        argtypes, args = [], []
+        for ptxt in params:
+            if "*" in ptxt:
+                argtypes.append(ctypes.c_void_p); args.append(None)
+            elif ptxt.startswith(("double", "const double")):
+                argtypes.append(ctypes.c_double); args.append(0.0)
+            elif ptxt.startswith(("float", "const float")):
+                argtypes.append(ctypes.c_float); args.append(0.0)
+            elif ptxt.startswith("size_t"):
+                argtypes.append(ctypes.c_size_t); args.append(0)
+            else:
+                argtypes.append(ctypes.c_int); args.append(0)
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argtypes, ctypes.c_int
+        if name == "vstab_destroy":   # destroying nothing is a no-op by contract
+            assert fn(*args) == 0
+            continue
+        rc = fn(*args)
+        msg = (lib.vstab_last_error() or b"").decode()
+        assert rc != 0, f"{name}(NULL ctx, zeros) returned 0"
+        assert "NULL" in msg or "null" in msg, f"{name}: message {msg!r} does not name the NULL argument"
+        checked += 1
+    assert checked >= 20
+
+
 def test_product_fails_loudly_without_gpu(pkg):
     import torch
 
