@@ -171,6 +171,54 @@ def test_c_abi_error_reporting(ctx):
         ctx.dis_flow_batch(torch.zeros((2, 6, 6), dtype=torch.uint8).cuda())
 
 
+def test_every_entry_point_rejects_empty_arguments(pkg):
+    """A live context with every other argument NULL / zero: each compute entry point returns a non-zero status with a
+    message before it launches anything, and the context is still usable afterwards."""
+    import ctypes
+
+    import torch
+
+    from tests.test_abi_cpu import header_prototypes
+    from vstab_amd import native
+
+    c = native.Context(0)
+    lib = c.lib
+    # calls that legitimately succeed with these arguments (zero-byte transfers are no-ops)
+    benign = {"vstab_destroy", "vstab_create", "vstab_set_stream", "vstab_synchronize", "vstab_set_timing", "vstab_dis_set_clip_start",
+              "vstab_upload", "vstab_download"}
+    checked = 0
+    for name, params in header_prototypes():
+        if not params or not params[0].startswith("vstab_ctx*") or name in benign:
+            continue
+        argtypes, args = [ctypes.c_void_p], [c.handle]
+        for ptxt in params[1:]:
+            if "*" in ptxt:
+                argtypes.append(ctypes.c_void_p); args.append(None)
+            elif ptxt.startswith(("double", "const double")):
+                argtypes.append(ctypes.c_double); args.append(0.0)
+            elif ptxt.startswith(("float", "const float")):
+                argtypes.append(ctypes.c_float); args.append(0.0)
+            elif ptxt.startswith("size_t"):
+                argtypes.append(ctypes.c_size_t); args.append(0)
+            else:
+                argtypes.append(ctypes.c_int); args.append(0)
+        fn = getattr(lib, name)
+        saved = (fn.argtypes, fn.restype)
+        fn.argtypes, fn.restype = argtypes, ctypes.c_int
+        try:
+            rc = fn(*args)
+        finally:
+            fn.argtypes, fn.restype = saved
+        msg = lib.vstab_last_error()
+        assert rc != 0 and msg, f"{name}(ctx, zeros) returned {rc} / {msg!r}"
+        checked += 1
+    assert checked >= 16
+    frames = torch.rand((1, 16, 24, 3))
+    dst, _, _ = c.warp_batch(frames, np.eye(3, dtype=np.float32)[None], (24, 16), border=BORDER)
+    assert torch.equal(dst.cpu(), frames)
+    c.close()
+
+
 def test_odd_output_sizes_and_single_pixel_frames(ctx, oracle):
     """Ragged shapes: 1-pixel-wide / 1-row sources, outputs not divisible by 4, output larger than source."""
     rng = np.random.default_rng(0)
