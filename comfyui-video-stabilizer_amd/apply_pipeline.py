@@ -230,12 +230,28 @@ def apply_motion(
         raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop_and_pad', 'crop', or 'expand'.")
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
-    if context.range_pending:   # F0's per-frame range sniff, on the device (stabilizer_utils.py:127-131)
-        if hm.resolve_value_range(context, ctx.frame_range(device_frames), ctx):
+    kw = dict(framing_mode=framing_mode, interpolation=interpolation, motion_blur=motion_blur, motion_blur_samples=motion_blur_samples)
+    if context.range_pending:
+        # F0's per-frame range sniff (stabilizer_utils.py:127-131), optimistically, as in the Flow node: the maxima pass
+        # (one 6.4 GB read, HBM-bound) runs on a second stream BESIDE the warp of the tensor as given (VALU-bound with
+        # motion blur) instead of in front of it; only if a frame turns out to be 0..255 data -- never for a ComfyUI
+        # IMAGE -- the frames are rescaled and the warp is repeated (its progress ticks were already emitted once).
+        torch = ctx.torch
+        main = torch.cuda.current_stream(ctx.device)
+        side = ctx.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            peaks = hm.prefetch_peaks(ctx.frame_range(device_frames))
+        frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
+                                                            progress_callback=progress_callback, **kw)
+        main.wait_stream(side)   # later work on the frames' memory stays ordered behind the maxima pass
+        if hm.resolve_value_range(context, peaks, ctx):
             device_frames = context.device_batch(ctx)
-    frames, masks, result_meta = apply_motion_on_device(
-        ctx, device_frames, 0, motion, meta, padding_rgb, framing_mode=framing_mode, interpolation=interpolation,
-        motion_blur=motion_blur, motion_blur_samples=motion_blur_samples, progress_callback=progress_callback)
+            frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
+                                                                progress_callback=None, **kw)
+    else:
+        frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
+                                                            progress_callback=progress_callback, **kw)
     if keep_on_device:
         return MotionApplyResult(frames, masks.unsqueeze(-1), result_meta)
     return MotionApplyResult(frames.cpu().numpy(), masks.cpu().numpy()[..., np.newaxis], result_meta)

@@ -250,6 +250,13 @@ class Context:
         except Exception:
             pass
 
+    def side_stream(self):
+        """A second torch stream of this context's device (created once): for a pass that may run beside the main work."""
+        s = getattr(self, "_side_stream", None)
+        if s is None:
+            s = self._side_stream = self.torch.cuda.Stream(device=self.device)
+        return s
+
     def use_torch_stream(self) -> None:
         stream = self.torch.cuda.current_stream(self.device)
         _check(self.lib.vstab_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), "vstab_set_stream")
