@@ -67,9 +67,10 @@ def camera_matrices(n: int, offset: int, width: int, height: int) -> np.ndarray:
     return out
 
 
-def synth_clip(n: int, offset: int, height: int, width: int, device, seed: int = 1234):
+def synth_clip(n: int, offset: int, height: int, width: int, device, seed: int = 1234, mats=None):
     """Band-limited procedural texture sampled analytically under the camera path (no interpolation):
-    frame_i(p) = T(M_i^-1 p).  Returns float32 [n,H,W,3] in [0.05,0.95] on `device`."""
+    frame_i(p) = T(M_i^-1 p).  Returns float32 [n,H,W,3] in [0.05,0.95] on `device`.
+    mats: explicit camera matrices [n,3,3] instead of camera_matrices(n, offset, ...)."""
     import torch
 
     rng = np.random.default_rng(seed)
@@ -78,8 +79,11 @@ def synth_clip(n: int, offset: int, height: int, width: int, device, seed: int =
     fy = torch.tensor(rng.uniform(-0.11, 0.11, k) * (1080.0 / height), device=device, dtype=torch.float32)
     ph = torch.tensor(rng.uniform(0, 6.28, (3, k)), device=device, dtype=torch.float32)
     amp = torch.tensor(rng.uniform(0.3, 1.0, k), device=device, dtype=torch.float32)
-    mats = camera_matrices(n, offset, width, height)
-    inv = torch.tensor(np.linalg.inv(mats), device=device, dtype=torch.float32)
+    if mats is None:
+        mats = camera_matrices(n, offset, width, height)
+    inv64 = np.linalg.inv(np.asarray(mats, np.float64))
+    projective = [bool(np.any(np.abs(m[2] / m[2, 2] - (0.0, 0.0, 1.0)) > 1e-15)) for m in inv64]
+    inv = torch.tensor(inv64, device=device, dtype=torch.float32)
     yy, xx = torch.meshgrid(torch.arange(height, device=device, dtype=torch.float32),
                             torch.arange(width, device=device, dtype=torch.float32), indexing="ij")
     out = torch.empty((n, height, width, 3), device=device, dtype=torch.float32)
@@ -88,6 +92,9 @@ def synth_clip(n: int, offset: int, height: int, width: int, device, seed: int =
         m = inv[i]
         X = m[0, 0] * xx + m[0, 1] * yy + m[0, 2]
         Y = m[1, 0] * xx + m[1, 1] * yy + m[1, 2]
+        if projective[i]:   # camera paths with perspective rows (tests / tools; the bench's own path is affine)
+            Wd = m[2, 0] * xx + m[2, 1] * yy + m[2, 2]
+            X, Y = X / Wd, Y / Wd
         arg = X[..., None] * fx + Y[..., None] * fy  # [H,W,k]
         for c in range(3):
             v = (torch.sin(arg + ph[c]) * amp).sum(-1) / norm
@@ -96,8 +103,65 @@ def synth_clip(n: int, offset: int, height: int, width: int, device, seed: int =
     return out
 
 
-def cpu_baseline(frames_host: np.ndarray, threads: int) -> dict:
-    """Time the CPU oracle (reference OpenCV path restated in C) over a bounded sample of the clip."""
+def transition_accuracy(full_res_matrices, cam: np.ndarray, size, work_size) -> dict:
+    """Error of reported transitions against the clip's analytic ones (independent of the oracle).
+
+    A texture point q shows at p_i = M_i q in frame i (synth_clip samples T(M_i^-1 p)), so the true transition is
+    A_i = M_{i+1} M_i^-1 (flow.py:133-210 estimates prev -> curr).  Errors are expressed at WORKING resolution (where DIS
+    ran): the displacement error |got(p) - A_i(p)| at the frame centre and its max over the four corners, in px, and
+    max |delta| over the 2x2 part (scale free)."""
+    got = np.asarray(full_res_matrices, np.float64).reshape(-1, 3, 3)
+    pairs = got.shape[0]
+    w, h = size
+    k = (work_size[0] / w) if work_size else 1.0   # working px per full-res px
+    pts = np.array([[w / 2, h / 2, 1.0], [0, 0, 1.0], [w - 1, 0, 1.0], [0, h - 1, 1.0], [w - 1, h - 1, 1.0]], np.float64).T
+    true = np.stack([cam[i + 1] @ np.linalg.inv(cam[i]) for i in range(pairs)])
+    pg = got @ pts
+    pt = true @ pts
+    pg = pg[:, :2] / pg[:, 2:3]
+    pt = pt[:, :2] / pt[:, 2:3]
+    err = np.hypot(*(pg - pt).transpose(1, 0, 2)) * k          # [P, 5] px at working res
+    centre, corner = err[:, 0], err[:, 1:].max(axis=1)
+    lin = np.abs(got[:, :2, :2] - true[:, :2, :2]).reshape(pairs, -1).max(axis=1)
+
+    def dist(v):
+        return {"max": float(v.max()), "mean": float(v.mean()), "p99": float(np.percentile(v, 99))}
+
+    return {"pairs": pairs, "centre_px": {k_: round(v, 5) for k_, v in dist(centre).items()},
+            "corner_px": {k_: round(v, 5) for k_, v in dist(corner).items()},
+            "lin_2x2": {k_: float(f"{v:.3e}") for k_, v in dist(lin).items()},
+            "true_motion_px": {"max": round(float((np.hypot(*(pt[:, :, 0] - pts[:2, 0]).T) * k).max()), 2)}}
+
+
+def static_texture_error(res, cam: np.ndarray, frames, device) -> dict:
+    """camera_lock + strength 1 (flow.py:356-371: target path 0): every output frame should show frame 0's view moved by
+    the crop_and_pad recentring shift, i.e. T((S M_0)^-1 p).  Error of the output against that analytically sampled
+    image over the pixels no frame padded (float 0..1 units)."""
+    import torch
+
+    n, h, w, _ = res.frames.shape
+    off = res.meta["framing"]["center_offset"]
+    shift = np.array([[1, 0, off[0]], [0, 1, off[1]], [0, 0, 1.0]])
+    want = synth_clip(1, 0, h, w, device, mats=(shift @ cam[0])[None])[0]
+    safe = (res.masks.reshape(n, h, w) == 0).all(dim=0)
+    # two pixels in from the padded region: a bilinear tap next to the border blends the padding colour in although the
+    # nearest-neighbour mask (flow.py:566-582) still calls the pixel covered
+    unsafe = torch.nn.functional.max_pool2d((~safe)[None, None].float(), 5, stride=1, padding=2)[0, 0] > 0
+    unsafe[:2] = unsafe[-2:] = True
+    unsafe[:, :2] = unsafe[:, -2:] = True
+    safe = ~unsafe
+    err = (res.frames - want[None]).abs().amax(dim=-1)          # [n,h,w]
+    err = torch.where(safe[None], err, torch.zeros_like(err))
+    per_frame = err.reshape(n, -1).amax(dim=1)
+    mse = float(((res.frames - want[None]) ** 2).mean(dim=-1)[:, safe].mean().item())
+    return {"frames": n, "safe_fraction": round(float(safe.float().mean().item()), 4), "max_abs": round(float(per_frame.max().item()), 5),
+            "mean_abs": round(float(err[:, safe].mean().item()), 6), "psnr_db": round(10 * np.log10(1.0 / max(mse, 1e-20)), 2),
+            "worst_frame": int(per_frame.argmax().item())}
+
+
+def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = False):
+    """Time the CPU oracle (reference OpenCV path restated in C) over a bounded sample of the clip.
+    keep_outputs: also hand back what the oracle computed (fits, plan matrices, warped pixels) for check_against_oracle."""
     os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import oracle as vo
 
@@ -117,7 +181,7 @@ def cpu_baseline(frames_host: np.ndarray, threads: int) -> dict:
     gray = vo.gray_for_estimation(frames_host, work)
     flow = vo.dis_flow_clip(gray)
     recs = [vo.fit_all_modes(flow[i], 8, "similarity")[0] for i in range(n - 1)]
-    work_mats, _, _, _, _ = fp.select_transitions(recs, "similarity")
+    work_mats, _, confs, resids, _ = fp.select_transitions(recs, "similarity")
     mats = [hm._rescale_transform_to_full(m, size, work) if work else m for m in work_mats]
     deltas = np.stack([hm._matrix_to_params(m, "similarity") for m in mats])
     path = np.concatenate([np.zeros((1, 4)), np.cumsum(deltas, axis=0)])
@@ -130,11 +194,79 @@ def cpu_baseline(frames_host: np.ndarray, threads: int) -> dict:
     x0, y0, x1, y1 = mins[:, 0].max(), mins[:, 1].max(), maxs[:, 0].min(), maxs[:, 1].min()
     shift = np.array([[1, 0, w * 0.5 - (x0 + x1) * 0.5], [0, 1, h * 0.5 - (y0 + y1) * 0.5], [0, 0, 1]], np.float32)
     final = np.stack([shift @ m for m in apply]).astype(np.float32)
-    vo.warp_clip(frames_host, final, size, border=hm.border_value((127, 127, 127)))
+    warped, mask, counts = vo.warp_clip(frames_host, final, size, border=hm.border_value((127, 127, 127)))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+    line = {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} frames of the same synthetic {w}x{h} clip, full path (range sniff, gray, DIS, fit, trajectory, "
                       f"warp+mask), OpenMP over frames, {dt:.1f} s"}
+    if not keep_outputs:
+        return line, None
+    return line, {"transitions": np.stack(mats), "confidences": confs, "residuals": resids, "final": final,
+                  "frames": warped, "masks": mask, "counts": counts}
+
+
+def check_against_oracle(meta, res_frames, res_masks, port: dict) -> dict:
+    """Parity AT THE BENCH SIZE (part of the cpu_baseline leg: the oracle is the checker, never the thing measured): the
+    HIP run's reported transitions / final matrices / pixels / masks / padding counts against what the CPU oracle computed
+    for the same clip.  Bit-equal or reported as a count of differing elements."""
+    em = meta["estimated_motion"]["per_transition"]
+    got_t = np.array([t["matrix"] for t in em], np.float32)
+    got_final = np.array([e["applied_matrix"] for e in meta["stabilization_warp"]["per_frame"]], np.float32)
+    n = got_final.shape[0]
+    out = {"frames": n,
+           "transition_matrices_equal": bool(np.array_equal(got_t, port["transitions"].astype(np.float32))),
+           "transition_matrices_max_abs_diff": float(np.abs(got_t - port["transitions"]).max()),
+           "confidences_equal": [t["confidence"] for t in em] == list(port["confidences"]),
+           "residuals_max_rel_diff": float(max(abs(t["residual"] - r) / max(abs(r), 1e-30) for t, r in zip(em, port["residuals"]))),
+           "final_matrices_max_abs_diff": float(np.abs(got_final - port["final"]).max())}
+    # the pixel comparison isolates the warp: oracle warp re-run with the HIP run's own matrices when those differ in
+    # the last bits (f32 plan arithmetic is numpy on both sides, so normally they do not)
+    ref_frames, ref_masks, ref_counts = port["frames"], port["masks"], port["counts"]
+    if not np.array_equal(got_final, port["final"]):
+        from oracle import oracle as vo
+        from vstab_amd import host_math as hm
+
+        out["pixels_checked_with"] = "oracle warp re-run on the HIP run's matrices"
+        ref_frames, ref_masks, ref_counts = vo.warp_clip(port["source"], got_final, tuple(meta["stabilization_warp"]["output_size"]),
+                                                         border=hm.border_value((127, 127, 127)))
+    f = res_frames.cpu().numpy()
+    m = res_masks.cpu().numpy().reshape(ref_masks.shape)
+    out["pixels_differing"] = int(np.count_nonzero(f != ref_frames))
+    out["mask_pixels_differing"] = int(np.count_nonzero(m != ref_masks))
+    ratios = (ref_counts.astype(np.float32) / np.float32(f.shape[1] * f.shape[2])).astype(np.float64)
+    out["padding_stats_equal"] = bool(meta["padding_fraction_mean"] == float(np.mean(ratios))
+                                      and meta["padding_fraction_max"] == float(np.max(ratios)))
+    out["bit_equal"] = bool(out["transition_matrices_equal"] and out["confidences_equal"] and out["pixels_differing"] == 0
+                            and out["mask_pixels_differing"] == 0 and out["padding_stats_equal"]
+                            and out["final_matrices_max_abs_diff"] == 0.0)
+    return out
+
+
+def check_batch_invariance(fp, hm, ctx, frames, meta, res_frames, pairs=(0, 127, 254)) -> dict:
+    """The per-pair results of the whole-clip run (fused DIS launch form, XCD block remap over the full grid, 64-bit
+    frame bases) against 2-frame runs of the same pairs (split launch form, tiny grids): HIP against HIP, so this is
+    not parity -- it shows that nothing depends on the batch size."""
+    em = meta["estimated_motion"]["per_transition"]
+    n = frames.shape[0]
+    ok, worst = True, 0.0
+    for p in pairs:
+        if p + 1 >= n:
+            continue
+        sub = fp._stabilize_frames(hm._normalize_video_input(frames[p:p + 2]), *FLOW_ARGS, ctx=ctx, keep_on_device=True)
+        t = sub.meta["estimated_motion"]["per_transition"][0]
+        same = t["matrix"] == em[p]["matrix"] and t["confidence"] == em[p]["confidence"] and t["residual"] == em[p]["residual"]
+        worst = max(worst, float(np.abs(np.array(t["matrix"]) - np.array(em[p]["matrix"])).max()))
+        ok = ok and same
+    # frames warped alone with the clip's matrices == the same frames of the whole-clip launch
+    final = np.array([e["applied_matrix"] for e in meta["stabilization_warp"]["per_frame"]], np.float32)
+    out_size = tuple(meta["stabilization_warp"]["output_size"])
+    px_ok = True
+    for i in sorted({0, n // 2 - 1, n - 1}):
+        dst, _, _ = ctx.warp_batch(frames[i:i + 1], final[i:i + 1], out_size, interp="bilinear",
+                                   border=hm.border_value((127, 127, 127)), want_mask=True, want_count=True)
+        px_ok = px_ok and bool((dst[0] == res_frames[i]).all().item())
+    return {"pairs": [p for p in pairs if p + 1 < n], "fit_records_equal": bool(ok), "fit_matrix_max_abs_diff": worst,
+            "frames_equal": px_ok}
 
 
 def launch_children(args, argv) -> int:
@@ -381,11 +513,31 @@ def main() -> int:
             },
         }
         if world == 1 and not use_dist:
+            cam = camera_matrices(n_local, 0, w, h)
+            work = hm._working_estimation_size(w, h)
+            chk_frames, chk_masks, chk_meta = step()   # one more pass, outside the timed region, kept for the checks
+            hip_t = [t["matrix"] for t in chk_meta["estimated_motion"]["per_transition"]]
+            line["accuracy"] = {"note": "reported transitions vs the clip's analytic M_{i+1} M_i^-1, errors in px at working "
+                                        "resolution (centre / worst corner displacement) and max |delta| of the 2x2 part",
+                                "hip": transition_accuracy(hip_t, cam, (w, h), work)}
+            try:
+                line["batch_invariance"] = check_batch_invariance(fp, hm, ctx, frames, chk_meta, chk_frames)
+            except Exception as exc:
+                line["batch_invariance"] = {"error": f"{type(exc).__name__}: {exc}"}
             if args.cpu_frames >= 2:
                 threads = min(16, len(os.sched_getaffinity(0)))
-                sample = frames[: min(args.cpu_frames, n_local)].cpu().numpy()
-                line["cpu_baseline"] = cpu_baseline(sample, threads)
-                del sample
+                n_cpu = min(args.cpu_frames, n_local)
+                sample = frames[:n_cpu].cpu().numpy()
+                line["cpu_baseline"], port = cpu_baseline(sample, threads, keep_outputs=(n_cpu == n_local))
+                if port is not None:
+                    line["accuracy"]["cpu_port"] = transition_accuracy(port["transitions"], cam, (w, h), work)
+                    port["source"] = sample
+                    try:
+                        line["parity_at_size"] = check_against_oracle(chk_meta, chk_frames, chk_masks, port)
+                    except Exception as exc:
+                        line["parity_at_size"] = {"error": f"{type(exc).__name__}: {exc}"}
+                del sample, port
+            del chk_frames, chk_masks
             if not args.no_extras:
                 try:
                     host = frames.cpu()

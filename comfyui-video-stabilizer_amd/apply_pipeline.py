@@ -14,6 +14,7 @@ import numpy as np
 
 from . import host_math as hm
 from . import native
+from .comfy_compat import check_interrupt
 from .meta_v2 import MotionMeta, motion_meta_from_stabilization_warp, resolve_motion_meta
 
 ProgressCallback = Callable[[], None]
@@ -80,6 +81,10 @@ def _warp(ctx, device_frames, matrices, output_size, interpolation, padding_rgb,
     n = device_frames.shape[0]
     total = len(matrices)
     border = hm.border_value(padding_rgb)
+    # cooperative cancel (flow.py:275-277 polls per frame; here once per batched launch -- the longest stretch that
+    # cannot be interrupted is one launch: ~50 ms for 256 x 1080p bicubic with 17 blur samples).  The progress ticks
+    # replayed after the launch are the second delivery point: ComfyUI's progress hook raises from update_absolute.
+    check_interrupt()
     if n == 0:   # a rank that owns no frames of the clip (multi-GPU, clip shorter than the world): shapes only
         empty = ctx.torch.empty((0, int(output_size[1]), int(output_size[0]), 3), dtype=ctx.torch.float32, device=ctx.device)
         return empty, empty[..., 0]
@@ -105,6 +110,7 @@ def _common_valid_mask(ctx, input_size, output_size, matrices, first, count, pro
     """AND over ALL frames of the clip of the nearest-neighbour coverage (motion_apply.py:205-227): coverage only, no
     pixels are read (vstab_common_coverage), so a shard evaluates the whole clip's matrices itself; it ticks for its
     own `count` frames."""
+    check_interrupt()
     m32 = np.stack([np.asarray(m, dtype=np.float32) for m in matrices])
     common = ctx.common_coverage(m32, input_size, output_size)
     _tick(progress_callback, count)
@@ -240,18 +246,25 @@ def apply_motion(
         main = torch.cuda.current_stream(ctx.device)
         side = ctx.side_stream()
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            peaks = hm.prefetch_peaks(ctx.frame_range(device_frames))
-        frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
-                                                            progress_callback=progress_callback, **kw)
-        main.wait_stream(side)   # later work on the frames' memory stays ordered behind the maxima pass
+        try:
+            with torch.cuda.stream(side):
+                peaks = hm.prefetch_peaks(ctx.frame_range(device_frames))
+            peaks.record_stream(main)   # allocated from the side stream's pool, consumed on the main stream below
+            frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
+                                                                progress_callback=progress_callback, **kw)
+        finally:
+            # also when the warp raised (validation, VstabError, a cancel delivered by a progress tick): the maxima
+            # pass still reads the frames, and the caller is free to drop them as soon as this frame unwinds
+            main.wait_stream(side)
         if hm.resolve_value_range(context, peaks, ctx):
+            check_interrupt()
             device_frames = context.device_batch(ctx)
             frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
                                                                 progress_callback=None, **kw)
     else:
         frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
                                                             progress_callback=progress_callback, **kw)
+    check_interrupt()
     if keep_on_device:
         return MotionApplyResult(frames, masks.unsqueeze(-1), result_meta)
     return MotionApplyResult(frames.cpu().numpy(), masks.cpu().numpy()[..., np.newaxis], result_meta)

@@ -11,9 +11,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <pthread.h>
 #include <sys/mman.h>
+#include <system_error>
 #include <thread>
 
 namespace {
@@ -32,13 +35,71 @@ int xfer_threads()
 
 // A team of host threads that walks the chunks of one transfer together: member 0 (the caller's thread) makes the HIP
 // calls, all members copy their 64-byte-aligned share of every chunk; two barrier waits per chunk.
+//
+// The helpers are started BEFORE the barrier is sized: a box that refuses a thread (process / thread limits) leaves a
+// smaller team -- down to the caller alone -- instead of an exception escaping an extern "C" function with started
+// helpers parked in a barrier nobody else will reach.
 struct Team {
-    int members;
+    int members = 1;
     pthread_barrier_t bar;
+    bool bar_ready = false;
     std::atomic<int> failed{0};
-    explicit Team(int n) : members(n) { pthread_barrier_init(&bar, nullptr, (unsigned)n); }
-    ~Team() { pthread_barrier_destroy(&bar); }
-    void sync() { pthread_barrier_wait(&bar); }
+    std::vector<std::thread> helpers;
+    std::mutex gate_m;
+    std::condition_variable gate_cv;
+    bool go = false;
+
+    Team() = default;
+    Team(const Team&) = delete;
+    ~Team()
+    {
+        release();
+        for (auto& th : helpers) th.join();
+        if (bar_ready) pthread_barrier_destroy(&bar);
+    }
+    void release()
+    {
+        {
+            std::lock_guard<std::mutex> lk(gate_m);
+            go = true;
+        }
+        gate_cv.notify_all();
+    }
+    // body(me) is run by every member; returns when all of them are done
+    template <class Body>
+    void run(int want, Body body)
+    {
+        // test knob: pretend the box refuses every helper after the first k (k >= 0)
+        const char* e = getenv("VSTAB_DEBUG_XFER_SPAWN_FAIL");
+        const int refuse_after = e ? atoi(e) : -1;
+        try {
+            for (int t = 1; t < want; t++) {
+                if (refuse_after >= 0 && t > refuse_after) throw std::system_error(EAGAIN, std::generic_category());
+                helpers.emplace_back([this, body, t] {
+                    std::unique_lock<std::mutex> lk(gate_m);
+                    gate_cv.wait(lk, [this] { return go; });
+                    lk.unlock();
+                    if (t < members) body(t);
+                });
+                members = t + 1;
+            }
+        } catch (const std::system_error&) {
+            // fewer helpers than asked for: members counts the ones that exist
+        }
+        if (pthread_barrier_init(&bar, nullptr, (unsigned)members) != 0) {
+            members = 1;   // no barrier: the caller's thread does all the copying, parked helpers fall through
+        } else {
+            bar_ready = true;
+        }
+        release();
+        body(0);
+        for (auto& th : helpers) th.join();
+        helpers.clear();
+    }
+    void sync()
+    {
+        if (members > 1) pthread_barrier_wait(&bar);
+    }
     void copy_share(int me, char* dst, const char* src, size_t bytes) const
     {
         const size_t part = (((bytes + members - 1) / members) + 63) & ~size_t(63);   // ceil: a tail shorter than the team is still copied
@@ -74,10 +135,16 @@ extern "C" int vstab_upload(vstab_ctx* ctx, const void* host_src, void* dev_dst,
     VSTAB_HIP(hipSetDevice(ctx->device));
     Ring r;
     if (ring_get(ctx, r)) return 1;
+    // dev_dst may be a block the caller's allocator handed back while its previous user is still queued on the
+    // context's stream (e.g. the frames of an earlier clip that a running blur warp still reads): order the copy
+    // stream behind everything launched so far, as vstab_download does
+    if (!ctx->ev_xfer_sync) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_xfer_sync, hipEventDisableTiming));
+    VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->stream));
+    VSTAB_HIP(hipStreamWaitEvent(ctx->xfer_stream, ctx->ev_xfer_sync, 0));
     const char* src = static_cast<const char*>(host_src);
     char* dst = static_cast<char*>(dev_dst);
     const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
-    Team team(bytes < (size_t(4) << 20) ? 1 : xfer_threads());
+    Team team;
     auto body = [&](int me) {
         for (size_t c = 0; c < chunks; c++) {
             const int s = (int)(c % SLOTS);
@@ -94,12 +161,7 @@ extern "C" int vstab_upload(vstab_ctx* ctx, const void* host_src, void* dev_dst,
             }
         }
     };
-    {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < team.members; t++) pool.emplace_back(body, t);
-        body(0);
-        for (auto& th : pool) th.join();
-    }
+    team.run(bytes < (size_t(4) << 20) ? 1 : xfer_threads(), body);
     VSTAB_REQUIRE(!team.failed, "vstab_upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
     // later work on the context's stream must see the data; the host may reuse / free host_src as soon as we return
     // (every byte has left it), and the ring is only touched again by a later call, which waits on these events
@@ -123,7 +185,7 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
     const char* src = static_cast<const char*>(dev_src);
     char* dst = static_cast<char*>(host_dst);
     const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
-    Team team(bytes < (size_t(4) << 20) ? 1 : xfer_threads());
+    Team team;
     // A freshly allocated output tensor is untouched memory: every 4 KiB page faults on first write, which is what
     // bounds this copy (not PCIe).  Ask for transparent huge pages on the 2 MiB-aligned interior -- 512x fewer faults
     // where the kernel grants it, no effect otherwise.
@@ -155,12 +217,7 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
             team.sync();
         }
     };
-    {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < team.members; t++) pool.emplace_back(body, t);
-        body(0);
-        for (auto& th : pool) th.join();
-    }
+    team.run(bytes < (size_t(4) << 20) ? 1 : xfer_threads(), body);
     VSTAB_REQUIRE(!team.failed, "vstab_download: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
     return vstab_check_device_status(ctx, "vstab_download");
 }

@@ -385,3 +385,47 @@ def test_one_hip_runtime_in_the_process(pkg):
     )
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def _plain(value):
+    """Enum-like members of either io implementation -> 'Enum.member' strings, as the fixture stores them."""
+    if isinstance(value, (str, int, float, bool, list, type(None))):
+        return value
+    name = getattr(value, "name", None)
+    return f"{type(value).__name__}.{name}" if name else str(value)
+
+
+def test_node_schema_contents_match_reference(pkg):
+    """everything the reference's define_schema bodies declare beyond the socket ids --
+    type, default, min, max, step, combo options, display_name, display_mode, control_after_generate, and the schema's
+    node_id / display_name / category / is_deprecated -- for all six nodes, against tests/golden/reference_schema.json
+    (generated by tests/golden/make_schema_golden.py from the imported reference classes:
+    video_stabilizer_flow.py:657-731, video_stabilizer_motion_apply.py:40-83, ...).  Free text (description, tooltip)
+    is UI documentation and may differ (the Classic node's "CPU-friendly" is not true of this build)."""
+    import json
+
+    from vstab_amd import nodes
+
+    golden = json.loads((ROOT / "tests" / "golden" / "reference_schema.json").read_text())
+    assert len(golden) == 6 and len(nodes.NODE_CLASSES) == 6
+    seen = set()
+    for cls in nodes.NODE_CLASSES:
+        s = cls.define_schema()
+        want = golden[s.node_id]
+        seen.add(s.node_id)
+        assert cls.__name__ == want["class"]
+        assert s.display_name == want["display_name"] and s.category == want["category"]
+        assert bool(getattr(s, "is_deprecated", False)) == bool(want.get("is_deprecated", False))
+        for got_list, want_list in ((s.inputs, want["inputs"]), (s.outputs, want["outputs"])):
+            assert [g.id for g in got_list] == [w["id"] for w in want_list], s.node_id
+            for g, w in zip(got_list, want_list):
+                where = f"{s.node_id}.{w['id']}"
+                assert g.kind == w["type"] and g.direction.lower() == w["direction"], where
+                declared = {k: _plain(v) for k, v in g.options.items() if k != "tooltip"}
+                expected = {k: v for k, v in w.items() if k not in ("type", "direction", "id", "tooltip")}
+                for enum_key in ("display_mode", "control_after_generate"):   # enum members: compared by member name
+                    for d in (declared, expected):
+                        if enum_key in d:
+                            d[enum_key] = str(d[enum_key]).split(".")[-1]
+                assert declared == expected, (where, declared, expected)
+    assert seen == set(golden)

@@ -115,3 +115,64 @@ def test_c5_flow_expand_then_motion_apply_expand_blur_ultra_4k(api, ctx, oracle)
     ref, ref_mask = oracle.warp_blur_clip(frames, expanded, (ew, eh), 0.5, 33, interp="bilinear", border=BORDER)
     assert np.array_equal(a_frames, ref), f"max diff {np.abs(a_frames - ref).max()}"
     assert np.array_equal(a_mask, ref_mask)
+
+
+def test_c2_at_baseline_frame_count_matches_oracle(api, ctx):
+    """BASELINE configs[1] AT ITS FRAME COUNT: the 256 x 1080p bench clip through
+    `_stabilize_frames` exactly as bench.py's timed step runs it, against the CPU oracle run over the same 256 frames:
+    all 255 reported transitions, confidences, final matrices, every output pixel, every mask pixel and the padding
+    statistics bit-equal; then HIP against HIP: pairs {0,127,254} as 2-frame clips (the split DIS launch form) and
+    frames {0,127,255} warped alone equal the whole-clip run (fused form chosen because 8 P >= 7 CUs, XCD block remap over
+    130 k blocks, 64-bit frame bases, the 628 MB workspace carve).  Bounds: none -- equality."""
+    import os
+
+    import torch
+
+    import bench
+
+    n, h, w = 256, 1080, 1920
+    frames = bench.synth_clip(n, 0, h, w, torch.device("cuda"))
+    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
+    meta = res.meta
+    assert meta["frames"] == n and meta["transform_mode_applied"] == "similarity"
+    inv = bench.check_batch_invariance(api.fp, api.hm, ctx, frames, meta, res.frames)
+    assert inv["fit_records_equal"] and inv["frames_equal"], inv
+    host = frames.cpu().numpy()
+    _, port = bench.cpu_baseline(host, min(16, len(os.sched_getaffinity(0))), keep_outputs=True)
+    port["source"] = host
+    chk = bench.check_against_oracle(meta, res.frames, res.masks, port)
+    assert chk["bit_equal"], chk
+    acc = bench.transition_accuracy([t["matrix"] for t in meta["estimated_motion"]["per_transition"]],
+                                    bench.camera_matrices(n, 0, w, h), (w, h), (960, 540))
+    # oracle-independent: the analytic motion of the bench clip is recovered (bounds: tests/test_analytic_gpu.py)
+    assert acc["corner_px"]["max"] < 0.1 and acc["lin_2x2"]["max"] < 2e-4, acc
+
+
+def test_c3_at_baseline_frame_count_sampled_frames_match_oracle(api, ctx, oracle):
+    """BASELINE configs[2] at 256 x 1080p: Flow perspective -> Motion Apply bicubic, blur 0.5, High (17 samples),
+    device-resident.  The Flow stage is checked on all 255 pairs against the oracle; the blurred output is checked
+    bit-exactly on frames {0, 1, 127, 254, 255}: a blurred frame depends on its own pixels and on its own and its
+    successor's matrix (the last frame: its predecessor's; motion_apply.py:125-134), so the oracle renders each sampled
+    frame from a 2-frame window of the clip."""
+    import torch
+
+    import bench
+    from vstab_amd import apply_pipeline as ap
+
+    n, h, w = 256, 1080, 1920
+    frames = bench.synth_clip(n, 0, h, w, torch.device("cuda"))
+    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), "crop_and_pad", "perspective", False, 0.7, 0.5, 0.6,
+                                   (127, 127, 127), 16.0, ctx=ctx, keep_on_device=True)
+    meta = res.meta
+    host = frames.cpu().numpy()
+    check_flow_stage(api, oracle, host, meta, "perspective")
+    del res
+    out = ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode="crop_and_pad",
+                          interpolation="bicubic", motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
+    m64 = np.array([e["matrix"] for e in meta["motion_meta"]["per_frame"]], np.float64)
+    for i in (0, 1, 127, 254, 255):
+        lo = min(i, n - 2)
+        ref, ref_mask = oracle.warp_blur_clip(host[lo:lo + 2], m64[lo:lo + 2], (w, h), 0.5, 17, interp="bicubic", border=BORDER)
+        k = i - lo
+        assert np.array_equal(out.frames[i].cpu().numpy(), ref[k]), i
+        assert np.array_equal(out.masks[i, ..., 0].cpu().numpy(), ref_mask[k]), i

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests.util import synth_frames
+from tests.util import test_matrices as make_matrices
 
 pytestmark = pytest.mark.gpu
 BORDER = np.array([127, 127, 127], np.float32) / 255.0
@@ -133,6 +134,8 @@ def test_error_texts(api, ctx):
     assert r.meta["motion_apply"]["framing_mode"] == "crop_and_pad"
 
 
+ANALYTIC_CORNER_PX, ANALYTIC_LIN = 0.1, 3e-4   # see the comment at their use
+
 FLOW_META_KEYS = ["frames", "transform_mode_requested", "transform_mode_applied", "camera_lock", "strength", "strength_effective",
                   "smooth", "fps_requested", "fps_effective", "framing", "keep_fov_applied", "padding_color_rgb", "flow_backend",
                   "flow_fallback_reason", "stabilization_warp", "estimated_motion", "padding_fraction_mean", "padding_fraction_max",
@@ -183,7 +186,9 @@ def test_flow_pipeline_against_oracle(api, ctx, oracle, size, mode, framing):
         tol = dict(rtol=2e-5, atol=1e-6) if mode == "perspective" else dict(rtol=0, atol=2e-5 if work else 1e-6)
         assert np.allclose(np.array(t["matrix"], np.float32), full, **tol)
         assert t["residual"] == pytest.approx(resids[i], rel=1e-6)
-    # known motion is recovered (independent of the oracle)
+    # known motion is recovered (independent of the oracle).  moving_clip() quantises an analytic texture to u8 gray and
+    # this test runs at working sizes down to 480x270 with a 48-wave texture; the tight bounds (<= 0.05 px, <= 1e-4) live
+    # in tests/test_analytic_gpu.py on float clips -- here: one tenth of a pixel anywhere in the frame
     def to_texture(pr):  # frame coords -> texture coords of moving_clip()
         tx, ty, th, sc = pr
         c, sn = np.cos(th) / sc, np.sin(th) / sc
@@ -192,11 +197,12 @@ def test_flow_pipeline_against_oracle(api, ctx, oracle, size, mode, framing):
         post = np.array([[1, 0, w / 2], [0, 1, h / 2], [0, 0, 1.0]])
         return post @ lin @ pre
 
-    for i, t in enumerate(em["per_transition"]):
-        expect = np.linalg.inv(to_texture(params[i + 1])) @ to_texture(params[i])
-        got = np.array(t["matrix"])
-        assert np.abs(got[:2, :2] - expect[:2, :2]).max() < (2e-2 if mode == "translation" else 3e-3)
-        assert np.abs(got[:2, 2] - expect[:2, 2]).max() < (2.5 if mode == "translation" else 0.8)
+    if mode != "translation":   # a translation model cannot represent the clip's rotation / zoom
+        import bench
+
+        cam = np.stack([np.linalg.inv(to_texture(p)) for p in params])
+        acc = bench.transition_accuracy([t["matrix"] for t in em["per_transition"]], cam, (w, h), work)
+        assert acc["corner_px"]["max"] < ANALYTIC_CORNER_PX and acc["lin_2x2"]["max"] < ANALYTIC_LIN, acc
     # --- warp vs oracle with the node's own matrices
     fm = np.array([e["applied_matrix"] for e in meta["stabilization_warp"]["per_frame"]], np.float32)
     out_size = tuple(meta["stabilization_warp"]["output_size"])
@@ -340,3 +346,98 @@ def test_value_range_sniff_is_settled_on_the_gpu(api, ctx):
     # single-frame passthrough settles the sniff on the host
     one = api.nodes.VideoStabilizerFlow.execute(torch.from_numpy(mixed[1:2].copy()), *args)
     assert np.array_equal(one[0].numpy(), expect_in[1:2])
+
+
+def test_upload_is_ordered_behind_running_kernels(ctx, api):
+    """ADVICE r2 (vstab_xfer.hip): an upload's destination may be a block the caching allocator handed back while a
+    kernel queued on the context's stream still reads it.  Clip A is blur-warped from host memory with the outputs kept
+    on the device; its device frames are dropped as apply_motion returns (the 17-sample warp is still running), and clip
+    B of the same size is uploaded at once -- it lands in A's block.  A's result must equal the result of a run that
+    synchronises before anything is reused."""
+    import torch
+
+    n, h, w = 6, 1080, 1920
+    a = torch.from_numpy(synth_frames(1, h, w, seed=3)).expand(n, h, w, 3).contiguous()
+    b = torch.zeros_like(a)
+    mats = make_matrices(n, w, h, "similarity", seed=4)
+    meta = block(api, list(mats), (w, h))
+
+    def run(sync_first):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        r = api.ap.apply_motion(api.hm._normalize_video_input(a), meta, (127, 127, 127), framing_mode="crop_and_pad",
+                                interpolation="bicubic", motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
+        if sync_first:
+            torch.cuda.synchronize()
+        other = ctx.upload(b)            # same size as A's freed device frames: the allocator returns that block
+        out = r.frames.cpu()
+        del other
+        return out
+
+    want = run(True)
+    got = run(False)
+    assert torch.equal(got, want)
+
+
+def test_transfers_survive_a_refused_helper_thread(ctx, monkeypatch):
+    """ADVICE r2: a box that refuses a std::thread must not take the process down (exception through extern "C",
+    helpers parked in a barrier): the team shrinks to the threads that exist, down to the caller alone."""
+    import torch
+
+    host = torch.arange((40 << 20) // 4, dtype=torch.int32)
+    for k in ("0", "1", "5"):
+        monkeypatch.setenv("VSTAB_DEBUG_XFER_SPAWN_FAIL", k)
+        dev = ctx.upload(host)
+        assert torch.equal(ctx.download(dev), host)
+
+
+class _Interrupted(Exception):
+    """Stand-in for comfy.model_management.InterruptProcessingException."""
+
+
+class _ManagementStub:
+    """comfy.model_management as the nodes see it: raises at the k-th poll (k = 1: the first one)."""
+
+    def __init__(self, raise_at):
+        self.raise_at, self.polls = raise_at, 0
+
+    def throw_exception_if_processing_interrupted(self):
+        self.polls += 1
+        if self.polls == self.raise_at:
+            raise _Interrupted()
+
+
+@pytest.mark.parametrize("raise_at", [1, 2])
+def test_cancel_leaves_both_nodes_reusable(api, ctx, monkeypatch, raise_at):
+    """Cooperative cancel (flow.py:275-277, 352, 594): ComfyUI's interrupt surfaces as an exception from
+    throw_exception_if_processing_interrupted().  It must propagate out of both nodes from every poll site, and the
+    shared context must compute the same results afterwards (no stream left waiting, no half-consumed status)."""
+    import torch
+    from vstab_amd import comfy_compat
+
+    frames = torch.from_numpy(synth_frames(6, 136, 240, seed=11))
+    flow_args = (frames, 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    clean = api.nodes.VideoStabilizerFlow.execute(*flow_args)
+    apply_args = (frames, {"motion_meta": clean[2]["motion_meta"]}, "crop", "bicubic", "#7F7F7F", 0.5, "High")
+    clean_apply = api.nodes.VideoStabilizerMotionApply.execute(*apply_args)
+
+    for node, args, want in ((api.nodes.VideoStabilizerFlow, flow_args, clean), (api.nodes.VideoStabilizerMotionApply, apply_args, clean_apply)):
+        stub = _ManagementStub(raise_at)
+        for mod in (comfy_compat, api.fp, api.ap):
+            if hasattr(mod, "model_management"):
+                monkeypatch.setattr(mod, "model_management", stub)
+        with pytest.raises(_Interrupted):
+            node.execute(*args)
+        assert stub.polls == raise_at
+        monkeypatch.setattr(comfy_compat, "model_management", None)
+        again = node.execute(*args)
+        assert torch.equal(again[0], want[0]) and torch.equal(again[1], want[1]) and again[2] == want[2]
+    # the polls of a whole run: Flow polls after the estimation and after the warp; Motion Apply (crop) before the
+    # coverage pass, before the warp launch and once after it
+    counter = _ManagementStub(-1)
+    monkeypatch.setattr(comfy_compat, "model_management", counter)
+    api.nodes.VideoStabilizerFlow.execute(*flow_args)
+    assert counter.polls >= 2
+    counter.polls = 0
+    api.nodes.VideoStabilizerMotionApply.execute(*apply_args)
+    assert counter.polls >= 3

@@ -252,3 +252,4 @@ def test_pipelined_upload_download_round_trip(ctx, nbytes):
     assert torch.equal(ctx.download(bumped), host + 1)
     again = ctx.upload(host[: max(1, n // 3)])   # the ring is reused by a later call while nothing else synchronised
     assert torch.equal(again.cpu(), host[: max(1, n // 3)])
+

@@ -62,3 +62,29 @@ def test_matrices(n, w, h, kind, seed=1):
             raise ValueError(kind)
         mats.append(m)
     return np.stack(mats).astype(np.float64)
+
+
+def shake_path(n, w, h, kind, seed=3, amp=1.0):
+    """Random-walk camera path [n,3,3] for bench.synth_clip(mats=...): translation / similarity / perspective increments
+    per frame, in full-resolution px scaled to the frame size (amp 1: up to +-6 x +-4 px, +-0.004 rad, +-0.3 % scale,
+    +-2e-6 / px of perspective per frame at 1920x1080)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 3, 3))
+    tx = ty = th = 0.0
+    sc = 1.0
+    px = py = 0.0
+    for i in range(n):
+        if i:
+            tx += rng.uniform(-6, 6) * amp * w / 1920
+            ty += rng.uniform(-4, 4) * amp * h / 1080
+            if kind != "translation":
+                th += rng.uniform(-0.004, 0.004) * amp
+                sc *= 1.0 + rng.uniform(-0.003, 0.003) * amp
+            if kind == "perspective":
+                px += rng.uniform(-2e-6, 2e-6) * amp * 1920 / w
+                py += rng.uniform(-2e-6, 2e-6) * amp * 1080 / h
+        c, s = np.cos(th) * sc, np.sin(th) * sc
+        pre = np.array([[1, 0, -w / 2], [0, 1, -h / 2], [0, 0, 1.0]])
+        post = np.array([[1, 0, w / 2 + tx], [0, 1, h / 2 + ty], [0, 0, 1.0]])
+        out[i] = post @ np.array([[c, -s, 0], [s, c, 0], [px, py, 1.0]]) @ pre
+    return out
