@@ -360,6 +360,7 @@ def main() -> int:
     ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
     ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
     ap_.add_argument("--no-extras", action="store_true", help="skip host_roundtrip / motion_apply (N=1 extras outside the timed loop)")
+    ap_.add_argument("--no-checks", action="store_true", help="skip accuracy / batch_invariance / parity_at_size (profiling runs: keeps the timed steps last in a trace)")
     args = ap_.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -515,20 +516,22 @@ def main() -> int:
         if world == 1 and not use_dist:
             cam = camera_matrices(n_local, 0, w, h)
             work = hm._working_estimation_size(w, h)
-            chk_frames, chk_masks, chk_meta = step()   # one more pass, outside the timed region, kept for the checks
-            hip_t = [t["matrix"] for t in chk_meta["estimated_motion"]["per_transition"]]
-            line["accuracy"] = {"note": "reported transitions vs the clip's analytic M_{i+1} M_i^-1, errors in px at working "
-                                        "resolution (centre / worst corner displacement) and max |delta| of the 2x2 part",
-                                "hip": transition_accuracy(hip_t, cam, (w, h), work)}
-            try:
-                line["batch_invariance"] = check_batch_invariance(fp, hm, ctx, frames, chk_meta, chk_frames)
-            except Exception as exc:
-                line["batch_invariance"] = {"error": f"{type(exc).__name__}: {exc}"}
+            checks = not args.no_checks
+            if checks:
+                chk_frames, chk_masks, chk_meta = step()   # one more pass, outside the timed region, kept for the checks
+                hip_t = [t["matrix"] for t in chk_meta["estimated_motion"]["per_transition"]]
+                line["accuracy"] = {"note": "reported transitions vs the clip's analytic M_{i+1} M_i^-1, errors in px at working "
+                                            "resolution (centre / worst corner displacement) and max |delta| of the 2x2 part",
+                                    "hip": transition_accuracy(hip_t, cam, (w, h), work)}
+                try:
+                    line["batch_invariance"] = check_batch_invariance(fp, hm, ctx, frames, chk_meta, chk_frames)
+                except Exception as exc:
+                    line["batch_invariance"] = {"error": f"{type(exc).__name__}: {exc}"}
             if args.cpu_frames >= 2:
                 threads = min(16, len(os.sched_getaffinity(0)))
                 n_cpu = min(args.cpu_frames, n_local)
                 sample = frames[:n_cpu].cpu().numpy()
-                line["cpu_baseline"], port = cpu_baseline(sample, threads, keep_outputs=(n_cpu == n_local))
+                line["cpu_baseline"], port = cpu_baseline(sample, threads, keep_outputs=(checks and n_cpu == n_local))
                 if port is not None:
                     line["accuracy"]["cpu_port"] = transition_accuracy(port["transitions"], cam, (w, h), work)
                     port["source"] = sample
@@ -537,7 +540,8 @@ def main() -> int:
                     except Exception as exc:
                         line["parity_at_size"] = {"error": f"{type(exc).__name__}: {exc}"}
                 del sample, port
-            del chk_frames, chk_masks
+            if checks:
+                del chk_frames, chk_masks
             if not args.no_extras:
                 try:
                     host = frames.cpu()

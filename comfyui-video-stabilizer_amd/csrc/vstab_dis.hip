@@ -345,7 +345,7 @@ struct PisArgs {
     float* Sx;             // [P][hs][ws]
     float* Sy;
     int n, w, h, ws, hs, stripe_sz;
-    int spin_limit;        // bound of the LDS progress-counter waits (VSTAB_DEBUG_PIS_SPIN_LIMIT overrides it in tests)
+    int spin_limit;        // a wavefront's total spin allowance over its LDS progress-counter waits (VSTAB_DEBUG_PIS_SPIN_LIMIT overrides it in tests)
     int* status;           // host-mapped status word of the context (vstab_internal.h): a timed-out wait is reported there
 };
 
@@ -357,15 +357,20 @@ struct PisArgs {
 // candidate -> bilinear window -> sums -> update never leaves the CU.
 constexpr int PIS_STRIPES_PER_BLOCK = 4;
 
-__device__ __forceinline__ void wait_progress(volatile int* counter, int need, int limit, int* status)
+__device__ __forceinline__ void wait_progress(volatile int* counter, int need, int& budget, int* status)
 {
     // bounded spin (every wave of the workgroup is resident, so the producer always makes progress; the bound turns a
     // logic error into a reported failure instead of a hung GPU: the wave records VSTAB_STATUS_PIS_TIMEOUT in the
     // context's host-visible status word and carries on, and the next host synchronisation point of the library
-    // (vstab_sample_fit_batch, vstab_synchronize) returns non-zero with vstab_last_error() set)
-    for (int spin = 0; spin < limit; spin++) {
+    // (vstab_sample_fit_batch, vstab_synchronize) returns non-zero with vstab_last_error() set).
+    // `budget` is the wavefront's TOTAL spin allowance for the kernel, not a per-wait one: a wave of the two-wavefront
+    // form waits up to 2 x ws ~ 120 times per level; with a per-wait bound of 2^22 spins (~0.3 s each at ~170 clocks per
+    // spin) waits expiring one after another could have stacked to ~40 s per level -- minutes per clip -- before the
+    // failure surfaced.  With one allowance a broken dependency costs a wave at most ~0.3 s per kernel.
+    while (budget > 0) {
         if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
         __builtin_amdgcn_s_sleep(1);
+        budget--;
     }
     if (__hip_atomic_load(const_cast<int*>(counter), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
     if (status != nullptr && (threadIdx.x & 63) == 0)
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_
     const float nn = (float)(PSZ * PSZ);
     const int lane_off4 = 2 * rr * w_ext + c2;
 
+    int spin_budget = a.spin_limit;   // all dependency waits of this wavefront together (see wait_progress)
     for (int iter = 0; iter < 2; iter++) {
         const int dir = (iter == 0) ? 1 : -1;
         const int start_is = (iter == 0) ? row_lo : row_hi - 1;
@@ -492,12 +498,12 @@ __global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_
             if (iter == 1) {
                 // the backward pass starts from each row's forward-pass result; the grouping (hence the wavefront that
                 // produced it) may differ between the passes, so wait for the forward pass of every row of the group
-                for (int q = 0; q < nq; q++) wait_progress(done0 + (row_a + dir * q), ws, a.spin_limit, a.status);
+                for (int q = 0; q < nq; q++) wait_progress(done0 + (row_a + dir * q), ws, spin_budget, a.status);
             }
             for (int s = 0; s < ws + nq - 1; s++) {
                 const int visited = s - Q;                             // patches this row finished before this step
                 const bool act = row_ok && visited >= 0 && visited < ws;
-                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, a.spin_limit, a.status);   // leading row's vertical neighbour (previous group)
+                if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, spin_budget, a.status);   // leading row's vertical neighbour (previous group)
                 if (act) {
                     const int js = start_js + dir * visited;
                     const int j = js * PSTR;
@@ -875,9 +881,18 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     const float* __restrict__ pIxz = b.Ixz; const float* __restrict__ pIyz = b.Iyz;
     // LDS tile: one float4 (dU, dV, smoothness weight, pad) per padded pixel -- an update reads its own and its
     // left / up neighbours' triples with one 16-B load each and the right / down increments with one 8-B load each
-    // (6 LDS instructions instead of 15), and only three loop-invariant addresses per owned pixel are live in the
+    // (6 LDS instructions instead of 15), and only four loop-invariant addresses per owned pixel are live in the
     // sweep loop instead of nine (three planes x own / up / down), which is what lets a thread own more pixels
     // without spilling.
+    //
+    // Layout: COLUMN-PARITY SEPARATED.  A padded row py is stored as two arrays of hw = ceil(pw / 2) entries, the even
+    // padded columns first, then the odd ones: pixel (py, px) sits at LIDX = (2 py + (px & 1)) hw + (px >> 1).  The
+    // pixels a half-sweep updates in one row all have the same column parity (a checkerboard colour), and consecutive
+    // lanes own consecutive ones, so every access of the update -- own, left / right (the other array of the row), up /
+    // down (the same array two row-slots away) -- runs at a 16-B lane stride: ds_read_b128 conflict-free, ds_read_b64 /
+    // ds_write_b64 2-way.  With the pixels in raster order (round 2) the stride was 32 B: 2-way on every b128, 4-way on
+    // the b64 reads and on the store -- 2.9 k of a half-sweep's 3.5 k cycles LDS-busy (profiles/r03_sor_lds_layout.md).
+    // Same values, same operations, same order: same bits.
     typedef float f4_t __attribute__((ext_vector_type(4)));
     typedef float f2_t __attribute__((ext_vector_type(2)));
     f4_t* lP = reinterpret_cast<f4_t*>(vr_lds);
@@ -907,6 +922,9 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             const int lw = min(ix1 + SOR_HALO, w) - ox, lh = min(iy1 + SOR_HALO, h) - oy;
             const int pw = lw + 2;                    // padded row length (1-px zero border)
             const int pn = pw * (lh + 2);
+            const int hw = (pw + 1) >> 1;             // entries per column-parity array of a padded row
+            const int rs2 = 2 * hw;                   // LDS distance of vertical neighbours
+#define LIDX(py_, px_) ((2 * (py_) + ((px_) & 1)) * hw + ((px_) >> 1))
             // ---- stage 1: zero border, load the increment, compute the smoothness weights into LDS
             for (int k = threadIdx.x; k < pn; k += blockDim.x) {
                 const int py = k / pw, px = k - py * pw;
@@ -924,7 +942,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                     const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
                     wv = div_plain(a.alpha2, sqrt_plain(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
                 }
-                lP[k] = f4_t{du, dv, wv, 0.f};
+                lP[LIDX(py, px)] = f4_t{du, dv, wv, 0.f};
             }
             __syncthreads();
             FUSED_MARK(3);
@@ -933,7 +951,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             const int ncol = lh * half_lw;
             float c11[2][SOR_NPT], c12[2][SOR_NPT], c22[2][SOR_NPT], cb1[2][SOR_NPT], cb2[2][SOR_NPT];
             float cy22[2][SOR_NPT];   // refined reciprocal of c22 (that of c11 rides in the LDS tile's spare float)
-            int cidx[2][SOR_NPT];
+            int cidx[2][SOR_NPT], cidl[2][SOR_NPT];   // LDS index of the owned pixel and of its left neighbour (right = left + 1)
             // Owned pixel j = 2*u + colour of this thread: k = threadIdx.x + u * FUSED_T = ly * half_lw + xh, advanced
             // incrementally (one division per tile).  The loop is NOT unrolled: one pixel's ~60 temporaries are live at a
             // time next to the persistent coefficient registers (an unrolled version interleaves the bodies and spills);
@@ -952,11 +970,21 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                         if (lx < lw) {
                             const int gx = ox + lx;
                             const int q = gy * w + gx;
-                            const int li = (ly + 1) * pw + lx + 1;
+                            const int li = LIDX(ly + 1, lx + 1), ll = LIDX(ly + 1, lx);
                             const float Ix = LDF(pIx, q), Iy = LDF(pIy, q), Iz = LDF(pIz, q), Ixx = LDF(pIxx, q), Ixy = LDF(pIxy, q),
                                         Iyy = LDF(pIyy, q), Ixz = LDF(pIxz, q), Iyz = LDF(pIyz, q);
                             const f4_t own = lP[li];
                             const float du = own.x, dv = own.y;
+                            // The flow of the four neighbours (smoothness term, below) is requested HERE, together with the
+                            // eight derivative planes, from clamped (always valid) positions: one wait for everything instead
+                            // of one dependent load-and-wait per neighbour after the data term (round 2 had each pair of loads
+                            // inside its `if (has_*)`: five serial memory round trips per pixel).
+                            const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
+                            const int q_r = has_r ? q + 1 : q, q_l = has_l ? q - 1 : q, q_d = has_d ? q + w : q, q_u = has_u ? q - w : q;
+                            const float uq = LDF(U, q), vq = LDF(V, q);
+                            const float u_r = LDF(U, q_r), v_r = LDF(V, q_r), u_l = LDF(U, q_l), v_l = LDF(V, q_l);
+                            const float u_d = LDF(U, q_d), v_d = LDF(V, q_d), u_u = LDF(U, q_u), v_u = LDF(V, q_u);
+                            const float wl = lP[ll].z, wu = lP[li - rs2].z;
                             float a11, a12, a22, B1, B2;
                             {
                                 float derivNorm = Ix * Ix + Iy * Iy + a.zeta2;
@@ -987,12 +1015,11 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             }
                             // smoothness term, accumulated in OpenCV's red/black scatter order.  `color` IS the global
                             // checkerboard parity (gx + gy) & 1 of the pixel, so the order is known at compile time.
-                            const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
-                            const float wq = own.z, uq = LDF(U, q), vq = LDF(V, q);
-#define SM_RIGHT() if (has_r) { B1 += wq * (LDF(U, q + 1) - uq); a11 += wq; B2 += wq * (LDF(V, q + 1) - vq); a22 += wq; }
-#define SM_LEFT()  if (has_l) { const float wl = lP[li - 1].z; B1 -= wl * (uq - LDF(U, q - 1)); a11 += wl; B2 -= wl * (vq - LDF(V, q - 1)); a22 += wl; }
-#define SM_DOWN()  if (has_d) { B1 += wq * (LDF(U, q + w) - uq); a11 += wq; B2 += wq * (LDF(V, q + w) - vq); a22 += wq; }
-#define SM_UP()    if (has_u) { const float wu = lP[li - pw].z; B1 -= wu * (uq - LDF(U, q - w)); a11 += wu; B2 -= wu * (vq - LDF(V, q - w)); a22 += wu; }
+                            const float wq = own.z;
+#define SM_RIGHT() if (has_r) { B1 += wq * (u_r - uq); a11 += wq; B2 += wq * (v_r - vq); a22 += wq; }
+#define SM_LEFT()  if (has_l) { B1 -= wl * (uq - u_l); a11 += wl; B2 -= wl * (vq - v_l); a22 += wl; }
+#define SM_DOWN()  if (has_d) { B1 += wq * (u_d - uq); a11 += wq; B2 += wq * (v_d - vq); a22 += wq; }
+#define SM_UP()    if (has_u) { B1 -= wu * (uq - u_u); a11 += wu; B2 -= wu * (vq - v_u); a22 += wu; }
                             if (color == 0) { SM_RIGHT() SM_LEFT() SM_DOWN() SM_UP() }
                             else            { SM_LEFT() SM_RIGHT() SM_UP() SM_DOWN() }
 #undef SM_RIGHT
@@ -1005,7 +1032,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
 #pragma unroll
                             for (int jj = 0; jj < 2 * SOR_NPT; jj++)
                                 if (jj == j) {
-                                    cidx[jj & 1][jj >> 1] = li;
+                                    cidx[jj & 1][jj >> 1] = li; cidl[jj & 1][jj >> 1] = ll;
                                     c11[jj & 1][jj >> 1] = a11; c12[jj & 1][jj >> 1] = a12; c22[jj & 1][jj >> 1] = a22;
                                     cb1[jj & 1][jj >> 1] = B1; cb2[jj & 1][jj >> 1] = B2;
                                     cy22[jj & 1][jj >> 1] = y22;
@@ -1033,8 +1060,9 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                     for (int u = 0; u < SOR_NPT; u++) {
                         const int li = cidx[color][u];
                         if (li >= 0) {
-                            const f4_t pc = lP[li], pl = lP[li - 1], pu = lP[li - pw];
-                            const f2_t pr = *reinterpret_cast<const f2_t*>(lP + li + 1), pd = *reinterpret_cast<const f2_t*>(lP + li + pw);
+                            const int ll = cidl[color][u];
+                            const f4_t pc = lP[li], pl = lP[ll], pu = lP[li - rs2];
+                            const f2_t pr = *reinterpret_cast<const f2_t*>(lP + ll + 1), pd = *reinterpret_cast<const f2_t*>(lP + li + rs2);
                             const float wq = pc.z, wl = pl.z, wu = pu.z;
                             const float sigmaU = wl * pl.x + wq * pr.x + wu * pu.x + wq * pd.x;
                             const float sigmaV = wl * pl.y + wq * pr.y + wu * pu.y + wq * pd.y;
@@ -1058,13 +1086,14 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
                 const int yy = k / iw, xx = k - yy * iw;
                 const int gx = ix0 + xx, gy = iy0 + yy;
-                const int li = (gy - oy + 1) * pw + (gx - ox + 1);
+                const int li = LIDX(gy - oy + 1, gx - ox + 1);
                 const f2_t uv = *reinterpret_cast<const f2_t*>(lP + li);
                 dOut_u[gy * w + gx] = uv.x;
                 dOut_v[gy * w + gx] = uv.y;
             }
             __syncthreads();
             FUSED_MARK(6);
+#undef LIDX
         }
         float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
         tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
@@ -1313,7 +1342,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             int tx = 1, ty = 1;
             auto tile_px = [&](int tx_, int ty_, int& padded) {
                 const int lw = std::min((g.w + tx_ - 1) / tx_ + 2 * SOR_HALO, g.w), lh = std::min((g.h + ty_ - 1) / ty_ + 2 * SOR_HALO, g.h);
-                padded = (lw + 2) * (lh + 2);
+                padded = 2 * ((lw + 3) / 2) * (lh + 2);   // two column-parity arrays of ceil((lw + 2) / 2) entries per padded row
                 return ((lw + 1) / 2) * lh;   // pixels of one colour
             };
             int padded = 0;

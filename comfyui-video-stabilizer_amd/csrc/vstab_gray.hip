@@ -80,9 +80,8 @@ __global__ __launch_bounds__(1024) void gray_area_int_kernel(const float* __rest
                     sum += gray_u8(cr, cg, cb, fused);
                     if (RANGE) {
                         vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fmaxf(cr, cg), cb));
-                        // a + b + c is NaN iff one of them is (or inf - inf, which a frame does not sensibly hold)
-                        const float probe = cr + cg + cb;
-                        has_nan |= (probe != probe) ? 1 : 0;
+                        // per component: a sum probe would also fire on +inf next to -inf, where numpy's max is +inf
+                        has_nan |= ((cr != cr) | (cg != cg) | (cb != cb)) ? 1 : 0;
                     }
                 }
                 // the K lanes of a box sit in one quad (blockDim.x and `used` are multiples of K): integer adds, any order
@@ -172,8 +171,7 @@ __global__ __launch_bounds__(256) void row_max_kernel(const float* __restrict__ 
         for (int k = threadIdx.x; k < nvec; k += 256) {
             const f4_t v = __builtin_nontemporal_load(R + k);   // read once by this pass (see gray_area_int_kernel)
             vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-            const float probe = (v.x + v.y) + (v.z + v.w);
-            has_nan |= (probe != probe) ? 1 : 0;
+            has_nan |= ((v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w)) ? 1 : 0;
         }
     } else {
         for (int k = threadIdx.x; k < row_floats; k += 256) {

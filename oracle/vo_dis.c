@@ -19,11 +19,12 @@
  *                             alpha 20, delta 5, gamma 10, zeta 0.1, epsilon 0.001
  *   upsample                  bilinear resize x2 between levels, final resize to full size, x4
  *
- * Deliberate, documented deviation from OpenCV's x86 build: the four per-patch sums
- * (sum d, sum d^2, sum d*Ix, sum d*Iy over the 8x8 patch) are reduced with a 6-level XOR
- * butterfly over lane = row*8 + col (what a 64-lane wavefront does with shuffles) instead of
- * OpenCV's 4-lane row accumulators + horizontal add.  The two orders differ only in f32
- * rounding of the same 64 terms.  Everything else keeps OpenCV's operation order.
+ * The four per-patch sums (sum d, sum d^2, sum d*Ix, sum d*Iy over the 8x8 patch) are reduced in OpenCV's own f32
+ * association -- the 4-lane row accumulators + horizontal add of the CV_SIMD128 branch (opencv_rows4_sum below); the
+ * HIP kernel reproduces it lane for lane.  (Round 1 shipped a 6-level XOR butterfly over lane = row*8 + col instead;
+ * it was measured outside the flow bound in round 2 and is kept behind vo_dis_set_sum_order(0) only so that
+ * tests/test_dis_sum_order_cpu.py can keep showing what it cost.)  No deliberate deviation from OpenCV's operation
+ * order remains.
  */
 #include "vo_common.h"
 #include "vstab_oracle.h"

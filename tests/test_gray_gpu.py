@@ -110,3 +110,18 @@ def test_frame_range_at_full_size(ctx):
     assert torch.equal(ctx.frame_range(dev).cpu(), want)
     _, peaks = ctx.gray_downscale(dev, (960, 540), want_range=True)
     assert torch.equal(peaks.cpu(), want)
+
+
+def test_range_sniff_with_both_infinities(ctx, oracle):
+    """a frame holding +inf and -inf has max +inf (numpy, stabilizer_utils.py:127-131: rescaled), not NaN
+    -- also when the two sit in one pixel / one 16-byte load, where a sum-based NaN probe would see inf - inf."""
+    frames = synth_frames(3, 270, 480, seed=2)
+    frames[0, 10, 10] = (np.inf, -np.inf, 0.25)          # one pixel: the gray pass probes per pixel
+    frames[1].reshape(-1)[8:12] = (np.inf, 0.5, -np.inf, 0.5)   # one aligned float4: the stand-alone pass probes per vector
+    frames[2, 5, 5, 0] = -np.inf
+    want = frames.reshape(3, -1).max(axis=1)
+    assert np.isposinf(want[0]) and np.isposinf(want[1]) and np.isfinite(want[2])
+    _, peaks = ctx.gray_downscale(frames, None, want_range=True)
+    assert np.array_equal(peaks.cpu().numpy(), want)
+    assert np.array_equal(ctx.frame_range(frames).cpu().numpy(), want)
+    assert np.array_equal(oracle.frame_max(frames), want)

@@ -1,5 +1,5 @@
 """Per-launch durations of the DIS kernels of the LAST bench step, in launch order, from a rocprofv3 kernel trace:
-     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-frames 0
+     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --steps 5 --warmup 2 --no-extras --no-checks --cpu-frames 0
      python3 tools/dis_level_times.py DIR"""
 import csv, glob, sys
 f = glob.glob(f'{sys.argv[1]}/**/*_kernel_trace.csv', recursive=True)[0]

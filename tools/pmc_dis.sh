@@ -5,13 +5,14 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
-OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
+OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT /tmp/pmc_dis_*; mkdir -p $OUT
 i=0
-# small groups (a six-counter pass once sat until its timeout on this pool); a failed pass ends the script: no further
-# GPU step after a timeout
+# small groups (a six-counter pass once sat until its timeout on this pool: profiles/r03_pmc_stuck_pass.md); a failed pass
+# ends the script (no further GPU step after a timeout) AFTER showing what the target had printed: pmc_target.py reports
+# its progress and the library's device status word (VSTAB_STATUS_PIS_TIMEOUT would show as a VstabError) line by line
 for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_dis_$i -- python3 $R/tools/pmc_target.py > $OUT/pass$i.log 2>&1 || { echo "pass failed: $grp"; exit 1; }
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_dis_$i -- python3 $R/tools/pmc_target.py > $OUT/pass$i.log 2>&1 || { echo "pass failed (rc $?): $grp"; echo "--- last lines of $OUT/pass$i.log"; tail -n 25 $OUT/pass$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

@@ -11,16 +11,24 @@ graft.load_package()
 import bench
 from vstab_amd import apply_pipeline as ap, flow_pipeline as fp, host_math as hm, native
 
+def say(msg):
+    print(f"[pmc_target] {msg}", flush=True)
+
+
 ctx = native.Context(0)
 frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
-for _ in range(2):
+say("clip ready")
+for k in range(2):
     r = fp._stabilize_frames(hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
     del r
+    ctx.synchronize()   # raises VstabError if a kernel left a bit in the device status word (an expired DIS wait)
+    say(f"flow pass {k} done, device status clean")
 meta = {"motion_meta": json.loads((ROOT / "tests" / "golden" / "shake_c3_256x1080p.json").read_text())}
 blk = meta["motion_meta"]
 blk["per_frame"] = blk["per_frame"][:64]
 blk["frame_count"] = 64
 r = ap.apply_motion(hm._normalize_video_input(frames[:64]), meta, (127, 127, 127), framing_mode="crop_and_pad", interpolation="bicubic",
                     motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
-torch.cuda.synchronize()
+ctx.synchronize()
+say("motion apply pass done, device status clean")
 print("done")
