@@ -116,6 +116,7 @@ def transition_accuracy(full_res_matrices, cam: np.ndarray, size, work_size) -> 
     k = (work_size[0] / w) if work_size else 1.0   # working px per full-res px
     pts = np.array([[w / 2, h / 2, 1.0], [0, 0, 1.0], [w - 1, 0, 1.0], [0, h - 1, 1.0], [w - 1, h - 1, 1.0]], np.float64).T
     true = np.stack([cam[i + 1] @ np.linalg.inv(cam[i]) for i in range(pairs)])
+    true = true / true[:, 2:3, 2:3]                                    # the reference reports homographies with h22 = 1
     pg = got @ pts
     pt = true @ pts
     pg = pg[:, :2] / pg[:, 2:3]
