@@ -40,6 +40,7 @@ struct WarpArgs {
     int tiles_x, tiles_y;
     int samples;      // 1 for the plain warp
     int nxf_per_frame;  // sample matrices stored per frame (1 for a single-frame blur clip)
+    int blur_fast;      // blur: the interior fast path may be used (host-checked preconditions, see warp_blur_kernel)
     float b0, b1, b2;   // border colour
 };
 
@@ -212,7 +213,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + i;
 }
 
-template <int INTERP, int SUBPIX, bool BLUR, bool WITH_MASK, int TILE_TX>
+template <int INTERP, int SUBPIX, bool WITH_MASK, int TILE_TX>
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 {
     constexpr int TILE_W = TILE_TX * TILE_PX, TILE_H = 256 / TILE_TX;
@@ -241,8 +242,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     const int npx = active ? (a.dw - x0 + TILE_TX - 1) / TILE_TX : 0;   // pixels x0 + p*TILE_TX < dw (capped at TILE_PX below)
 
     const float* __restrict__ S = a.src + (size_t)frame * a.sh * a.sw * 3;
-    const int S_count = BLUR ? a.samples : 1;
-    const int nxf = BLUR ? a.nxf_per_frame : 1;
+    constexpr int nxf = 1;   // one matrix per frame (the S-sample blur is warp_blur_kernel)
 
     float acc[TILE_PX][3];
     float cov[TILE_PX];
@@ -318,9 +318,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
                         c = ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
                     }
                 }
-                if (BLUR) { acc[p][0] += v.r; acc[p][1] += v.g; acc[p][2] += v.b; }
-                else { acc[p][0] = v.r; acc[p][1] = v.g; acc[p][2] = v.b; }
-                if (WITH_MASK) { if (BLUR) cov[p] += c; else cov[p] = c; }
+                acc[p][0] = v.r; acc[p][1] = v.g; acc[p][2] = v.b;
+                if (WITH_MASK) cov[p] = c;
             }
         }
     }
@@ -328,21 +327,11 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     // ---- epilogue ----
     float mk[TILE_PX];
     unsigned padded = 0;
-    if (BLUR) {
-        const float fs = (float)S_count;
 #pragma unroll
-        for (int p = 0; p < TILE_PX; p++) {
-            acc[p][0] = acc[p][0] / fs; acc[p][1] = acc[p][1] / fs; acc[p][2] = acc[p][2] / fs;
-            float m = 1.0f - cov[p] / fs;
-            mk[p] = (m < 1e-3f) ? 0.f : m;
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < TILE_PX; p++) {
-            float m = 1.0f - cov[p];
-            mk[p] = (m < 1e-3f) ? 0.f : m;
-            if (WITH_MASK && p < npx) padded += (mk[p] > 0.5f) ? 1u : 0u;
-        }
+    for (int p = 0; p < TILE_PX; p++) {
+        float m = 1.0f - cov[p];
+        mk[p] = (m < 1e-3f) ? 0.f : m;
+        if (WITH_MASK && p < npx) padded += (mk[p] > 0.5f) ? 1u : 0u;
     }
 
     if (active) {
@@ -363,7 +352,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
         }
     }
 
-    if (WITH_MASK && !BLUR && a.pad_count != nullptr) {
+    if (WITH_MASK && a.pad_count != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) padded += __shfl_down(padded, off);
         if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = padded;
@@ -375,13 +364,302 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
     }
 }
 
-template <int INTERP, int SUBPIX, bool BLUR>
+// ---- motion blur: S samples per output pixel (motion_apply.py:137-202) ---------------------------------------------
+//
+// What bounds the S-sample loop (profiles/r03_blur_kernel.md): a bicubic sample reads 16 taps x 12 B = 192 B per output
+// pixel; served by the CU's vector L1 at 64 B per clock that is 3 clocks per pixel-sample -- 12.6 ms for 64 x 1080p x 17
+// samples at 2.2 GHz, which is what round 2's kernel took (12.6 ms) and what every rearrangement of its arithmetic took
+// too (fewer bounds tests, shared block-origin terms, product table, scalar-base addressing: 12.85-12.88 ms each).  The
+// VALU work (176 instructions per pixel-sample, 84 % issue) was only just hidden behind it.  The loop is therefore fed
+// from LDS (256 B per clock) instead:
+//
+//   * A block owns a 64 x TILE_H output tile for ALL samples.  Once per block, the source coordinates of the tile's four
+//     corners are evaluated for every sample with the kernel's own arithmetic (4 x S threads).  For affine samples the
+//     per-pixel evaluation is monotone in x and in y (a chain of correctly rounded operations, same column-block origin
+//     for the whole tile), so the corner values bound every pixel's: their bounding box + the tap footprint is the
+//     source window the tile can touch.  If all samples are affine, the window lies inside the source and fits the LDS
+//     budget, the block stages it (each texel read from memory once, padded to a float4) and runs the STAGED loop;
+//     otherwise (border tiles, perspective samples, very fast motion) it runs the general loop (sample_q5), which is
+//     the arithmetic definition.  Both give the oracle's bits (tests/test_warp_gpu.py, tests/test_configs_gpu.py).
+//   * The staged loop has no bounds tests, no short saturation (no-ops in the interior) and no coverage arithmetic
+//     (all S samples covered: mask = 1 - S/S = 0, the float the general loop produces); the f64 block-origin terms
+//     X0, Y0 are formed once per thread and sample, not per pixel; taps are 16-byte LDS reads at a 16-byte lane stride.
+//   * bilinear: the four tap weights come from the 32 x 32 table of PRODUCTS in LDS (what OpenCV's remap reads:
+//     initInterTab2D), 16 KB; bicubic keeps the 1-D table + 16 products per sample: its 64 KB product table would
+//     halve the blocks per CU for 16 of ~140 instructions.
+template <int INTERP, int SUBPIX>
+struct BlurGeom {
+    static constexpr bool FAST = SUBPIX == VSTAB_SUBPIX_Q5;
+    static constexpr bool BICUBIC = INTERP == VSTAB_INTERP_BICUBIC;
+    static constexpr int NT = 512;                                    // 64 x 16 output pixels
+    static constexpr int TAB_FLOATS = (FAST && !BICUBIC) ? 32 * 32 * 4 : 0;   // bilinear product table
+    static constexpr int FOOT_TEXELS = !FAST ? 0 : (BICUBIC ? 4864 : 2304);   // staged source window (float4 per texel)
+    static constexpr int TAPS = BICUBIC ? 4 : 2, LEAD = BICUBIC ? 1 : 0;      // taps per axis, taps left of / above (sx, sy)
+    // LDS per block: bicubic 76 KB + 0.5 KB (two blocks per CU), bilinear 16 + 36 + 0.5 KB (three)
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)TAB_FLOATS + 32 * 4 + (size_t)FOOT_TEXELS * 4);
+};
+
+// amdgpu_waves_per_eu(4): at most 128 VGPRs, so that two 512-thread bicubic blocks share a CU.
+// `xfs` is a kernel argument of its own (not the WarpArgs member): a `const T* __restrict__` PARAMETER is what lets the
+// compiler read the per-sample matrices with scalar loads (s_load into SGPRs) -- through the by-value struct it used
+// per-lane vector loads, a full memory round trip at the head of every sample's dependent chain.
+template <int INTERP, int SUBPIX, bool WITH_MASK>
+__global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdgpu_waves_per_eu(4))) void warp_blur_kernel(WarpArgs a, const WarpXform* __restrict__ xfs)
+{
+    using G = BlurGeom<INTERP, SUBPIX>;
+    constexpr int NT = G::NT, TILE_TX = 32, TILE_W = TILE_TX * TILE_PX, TILE_H = NT / TILE_TX;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];   // [product table][1-D cubic table][staged window]
+    float* s_tab = s_mem;
+    float* s_cub = s_mem + G::TAB_FLOATS;
+    f4_t* s_foot = reinterpret_cast<f4_t*>(s_mem + G::TAB_FLOATS + 32 * 4);
+    __shared__ int s_box[4];   // min sx, min sy, max sx, max sy over corners x samples
+    const float* cub_tab = nullptr;
+    if (INTERP == VSTAB_INTERP_BICUBIC) {
+        if (threadIdx.x < 32) cubic_coeffs((int)threadIdx.x, s_cub + threadIdx.x * 4);
+        cub_tab = s_cub;
+    }
+    if (G::TAB_FLOATS) {
+        for (int e = threadIdx.x; e < 1024; e += NT) {
+            const int fy = e >> 5, fx = e & 31;
+            const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1;
+            const float wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
+            reinterpret_cast<f4_t*>(s_tab)[e] = f4_t{wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+        }
+    }
+    if (threadIdx.x == 0) { s_box[0] = s_box[1] = 0x7fffffff; s_box[2] = s_box[3] = (int)0x80000000; }
+    __syncthreads();
+
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tiles_per_frame = (unsigned)a.tiles_x * a.tiles_y;
+    const int frame = t / tiles_per_frame;
+    const unsigned tr = t - frame * tiles_per_frame;
+    const int tile_y = tr / a.tiles_x, tile_x = tr - tile_y * a.tiles_x;
+    const int tx = threadIdx.x % TILE_TX, ty = threadIdx.x / TILE_TX;
+    const int x0 = tile_x * TILE_W + tx;
+    const int y = tile_y * TILE_H + ty;
+    const bool active = (y < a.dh) && (x0 < a.dw);
+    const int npx = active ? (a.dw - x0 + TILE_TX - 1) / TILE_TX : 0;
+    const float* __restrict__ S = a.src + (size_t)frame * a.sh * a.sw * 3;
+    const int nxf = a.nxf_per_frame;
+    const WarpXform* __restrict__ xf0 = xfs + (size_t)frame * nxf;
+
+    auto block_origin = [&](int x) {
+        if (a.bw0 >= a.dw) return 0;
+        if (a.bw0_pow2) return x & ~(a.bw0 - 1);
+        return (x / a.bw0) * a.bw0;
+    };
+
+    // ---- the source window this tile can touch, over all samples
+    bool fast = G::FAST && a.blur_fast != 0;
+    int ox = 0, oy = 0, fw = 0;
+    if (fast) {
+        bool ok = true;
+        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+        if ((int)threadIdx.x < 4 * nxf) {
+            const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
+            const WarpXform* __restrict__ xf = xf0 + k;
+            const int cx_ = (c & 1) ? min(tile_x * TILE_W + TILE_W, a.dw) - 1 : tile_x * TILE_W;
+            const int cy_ = (c & 2) ? min(tile_y * TILE_H + TILE_H, a.dh) - 1 : tile_y * TILE_H;
+            const int xb = block_origin(cx_);
+            const double dxb = (double)xb, dyc = (double)cy_, dx1 = (double)(cx_ - xb);
+            const double Xn = (xf->m[0] * dxb + xf->m[1] * dyc + xf->m[2]) + xf->m[0] * dx1;
+            const double Yn = (xf->m[3] * dxb + xf->m[4] * dyc + xf->m[5]) + xf->m[3] * dx1;
+            const double Xq = Xn * xf->wq, Yq = Yn * xf->wq;
+            ok = xf->affine != 0 && __builtin_fabs(Xq) < 9.0e5 && __builtin_fabs(Yq) < 9.0e5;   // NaN compares false
+            if (ok) { bx0 = bx1 = round_small(Xq) >> 5; by0 = by1 = round_small(Yq) >> 5; }
+        }
+        // bounding box: butterfly over the wavefront (idle lanes hold the neutral elements), one LDS atomic set per wavefront
+        if ((int)(threadIdx.x & ~63u) < 4 * nxf) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
+                bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0);
+                atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+            }
+        }
+        fast = __syncthreads_and(ok) != 0;
+        if (fast) {
+            // taps of (sx, sy): columns sx - LEAD .. sx - LEAD + TAPS - 1; one texel of margin on every side
+            ox = s_box[0] - G::LEAD - 1;
+            oy = s_box[1] - G::LEAD - 1;
+            fw = s_box[2] - s_box[0] + G::TAPS + 2;
+            const int fh = s_box[3] - s_box[1] + G::TAPS + 2;
+            fast = ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh && fw * fh <= G::FOOT_TEXELS;   // uniform
+            if (fast) {
+                // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row
+                typedef float f3_t __attribute__((ext_vector_type(3), aligned(4)));
+                for (int i = threadIdx.x; i < fw * fh; i += NT) {
+                    const int r = i / fw, c = i - r * fw;
+                    const f3_t v = *reinterpret_cast<const f3_t*>(S + ((unsigned)(oy + r) * (unsigned)a.sw + (unsigned)(ox + c)) * 3u);
+                    s_foot[i] = f4_t{v.x, v.y, v.z, 0.f};
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    float acc[TILE_PX][3];
+    float cov[TILE_PX];
+#pragma unroll
+    for (int p = 0; p < TILE_PX; p++) { acc[p][0] = acc[p][1] = acc[p][2] = 0.f; cov[p] = 0.f; }
+
+    if (active && fast) {
+        const int xb = block_origin(x0);                 // == block_origin(x0 + TILE_TX): blur_fast
+        const double dy = (double)y, dxb = (double)xb;
+        // a pixel of this thread beyond the right edge (ragged last tile) re-evaluates pixel 0 instead of being skipped:
+        // no divergent branch inside the sample loop, its sum is never stored
+        double dx1[TILE_PX];
+#pragma unroll
+        for (int p = 0; p < TILE_PX; p++) dx1[p] = (double)((p < npx ? x0 + p * TILE_TX : x0) - xb);
+        const int tap0 = (oy + G::LEAD) * fw + ox + G::LEAD;   // window index of tap (0,0) = (sy * fw + sx) - tap0
+        for (int k = 0; k < nxf; k++) {
+            const WarpXform* __restrict__ xf = xf0 + k;
+            const double m0 = xf->m[0], m3 = xf->m[3], wq = xf->wq;
+            const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
+            const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) {
+                const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
+                const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
+                const int sx = X >> 5, sy = Y >> 5;
+                const int fx = X & 31, fy = Y & 31;
+                const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)sy, (unsigned)fw) + sx - tap0);
+                if (INTERP == VSTAB_INTERP_BICUBIC) {
+                    const f4_t cxv = reinterpret_cast<const f4_t*>(s_cub)[fx], cyv = reinterpret_cast<const f4_t*>(s_cub)[fy];
+                    const float cx[4] = {cxv.x, cxv.y, cxv.z, cxv.w}, cy[4] = {cyv.x, cyv.y, cyv.z, cyv.w};
+                    float sr = 0.f, sg = 0.f, sb = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const f4_t t0 = T[i * fw], t1 = T[i * fw + 1], t2 = T[i * fw + 2], t3 = T[i * fw + 3];
+                        const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+                        const float tr_ = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
+                        const float tg_ = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
+                        const float tb_ = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
+                        if (i == 0) { sr = tr_; sg = tg_; sb = tb_; }
+                        else { sr += tr_; sg += tg_; sb += tb_; }
+                    }
+                    acc[p][0] += sr; acc[p][1] += sg; acc[p][2] += sb;
+                } else {
+                    const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
+                    const f4_t w = reinterpret_cast<const f4_t*>(s_tab)[fy * 32 + fx];
+                    acc[p][0] += t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
+                    acc[p][1] += t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
+                    acc[p][2] += t00.z * w.x + t01.z * w.y + t10.z * w.z + t11.z * w.w;
+                }
+            }
+        }
+        if (WITH_MASK) {
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) cov[p] = (float)nxf;   // every sample covered: 1.f added nxf times
+        }
+    } else if (active) {
+        const double dy = (double)y;
+        for (int k = 0; k < nxf; k++) {
+            const WarpXform* __restrict__ xf = xf0 + k;
+            const double m0 = xf->m[0], m1 = xf->m[1], m2 = xf->m[2];
+            const double m3 = xf->m[3], m4 = xf->m[4], m5 = xf->m[5];
+            const double m6 = xf->m[6], m7 = xf->m[7], m8 = xf->m[8];
+            const bool affine = xf->affine != 0;
+            float mf[9];
+            if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
+            }
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) {
+                if (p >= npx) continue;
+                const int x = x0 + p * TILE_TX;
+                const int xb = block_origin(x);
+                const double dxb = (double)xb;
+                const double X0 = m0 * dxb + m1 * dy + m2;
+                const double Y0 = m3 * dxb + m4 * dy + m5;
+                const double W0 = m6 * dxb + m7 * dy + m8;
+                const double dx1 = (double)(x - xb);
+                const double Xn = X0 + m0 * dx1, Yn = Y0 + m3 * dx1;
+                double Wq, Wn;
+                if (affine) { Wq = xf->wq; Wn = xf->wn; }
+                else {
+                    const double W = W0 + m6 * dx1;
+                    Wn = (W != 0.0) ? 1.0 / W : 0.0;
+                    Wq = 32.0 * Wn;
+                }
+                Px v;
+                if (SUBPIX == VSTAB_SUBPIX_EXACT && INTERP == VSTAB_INTERP_BILINEAR) {
+                    const float w = x * mf[6] + y * mf[7] + mf[8];
+                    const float fsx = (x * mf[0] + y * mf[1] + mf[2]) / w;
+                    const float fsy = (x * mf[3] + y * mf[4] + mf[5]) / w;
+                    v = sample_exact(S, a.sh, a.sw, fsx, fsy, a.b0, a.b1, a.b2);
+                } else {
+                    const int X = clamp_round_i32(Xn * Wq);
+                    const int Y = clamp_round_i32(Yn * Wq);
+                    v = sample_q5<INTERP>(S, a.sh, a.sw, X, Y, a.b0, a.b1, a.b2, cub_tab);
+                }
+                acc[p][0] += v.r; acc[p][1] += v.g; acc[p][2] += v.b;
+                if (WITH_MASK) {
+                    const int nx = sat_short(clamp_round_i32(Xn * Wn));
+                    const int ny = sat_short(clamp_round_i32(Yn * Wn));
+                    cov[p] += ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
+                }
+            }
+        }
+    }
+
+    if (active) {
+        const float fs = (float)a.samples;   // the reference divides by the sample count even when a 1-frame clip yields one sample
+        float* __restrict__ D = a.dst + (size_t)frame * a.dh * a.dw * 3;
+        float* __restrict__ Mk = WITH_MASK ? a.mask + (size_t)frame * a.dh * a.dw : nullptr;
+        const unsigned row = (unsigned)y * (unsigned)a.dw;
+        typedef float f3 __attribute__((ext_vector_type(3)));
+#pragma unroll
+        for (int p = 0; p < TILE_PX; p++) {
+            if (p >= npx) continue;
+            const unsigned pix = row + (unsigned)(x0 + p * TILE_TX);
+            f3 rgb = {acc[p][0] / fs, acc[p][1] / fs, acc[p][2] / fs};
+            __builtin_memcpy(D + pix * 3u, &rgb, 12);
+            if (WITH_MASK) {
+                const float m = 1.0f - cov[p] / fs;
+                Mk[pix] = (m < 1e-3f) ? 0.f : m;
+            }
+        }
+    }
+}
+
+template <int INTERP, int SUBPIX>
+int launch_blur(WarpArgs a, bool with_mask, hipStream_t st)
+{
+    using G = BlurGeom<INTERP, SUBPIX>;
+    constexpr int TILE_W = 32 * TILE_PX, TILE_H = G::NT / 32;
+    a.tiles_x = (a.dw + TILE_W - 1) / TILE_W;
+    a.tiles_y = (a.dh + TILE_H - 1) / TILE_H;
+    const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
+    VSTAB_REQUIRE(blocks > 0 && blocks < 0x7fffffffULL, "warp: grid of %llu blocks is out of range", blocks);
+    // fast-path preconditions that do not depend on the block: a thread's two pixels share OpenCV's column block, a
+    // frame's byte offsets fit 32 bits, u24 multiplies are exact (check_common: sh, sw <= 32767)
+    a.blur_fast = ((a.bw0 >= a.dw) || (a.bw0 % TILE_W == 0)) && ((unsigned long long)a.sh * a.sw * 12ULL < (1ULL << 32)) ? 1 : 0;
+    if (const char* e = getenv("VSTAB_BLUR_FAST")) a.blur_fast = a.blur_fast && atoi(e) != 0;   // 0: general loop everywhere (tests, A/B)
+    const size_t lds = G::LDS_BYTES;
+    if (with_mask) {
+        if (lds > 64 * 1024) VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, true>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
+    } else {
+        if (lds > 64 * 1024) VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, false>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
+    }
+    VSTAB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int INTERP, int SUBPIX>
 void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t st, int tx)
 {
 #define LAUNCH_TX(TX)                                                                                              \
     do {                                                                                                           \
-        if (with_mask) hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, true, TX>), dim3(grid), dim3(256), 0, st, a);  \
-        else hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, BLUR, false, TX>), dim3(grid), dim3(256), 0, st, a);  \
+        if (with_mask) hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, true, TX>), dim3(grid), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((warp_kernel<INTERP, SUBPIX, false, TX>), dim3(grid), dim3(256), 0, st, a);  \
     } while (0)
     if (tx == 16) LAUNCH_TX(16);
     else if (tx == 64) LAUNCH_TX(64);
@@ -390,7 +668,6 @@ void launch_mask(const WarpArgs& a, bool with_mask, unsigned grid, hipStream_t s
 #undef LAUNCH_TX
 }
 
-template <bool BLUR>
 int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t st)
 {
     // threads along x of the 256-thread tile: 32 (64 x 8 px) by default; VSTAB_WARP_TX = 8|16|64 for sweeps
@@ -402,11 +679,18 @@ int launch_warp(WarpArgs a, int interp, int subpix, bool with_mask, hipStream_t 
     const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
     VSTAB_REQUIRE(blocks > 0 && blocks < 0x7fffffffULL, "warp: grid of %llu blocks is out of range", blocks);
     const unsigned grid = (unsigned)blocks;
-    if (interp == VSTAB_INTERP_BICUBIC) launch_mask<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st, tx);
-    else if (subpix == VSTAB_SUBPIX_EXACT) launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT, BLUR>(a, with_mask, grid, st, tx);
-    else launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5, BLUR>(a, with_mask, grid, st, tx);
+    if (interp == VSTAB_INTERP_BICUBIC) launch_mask<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5>(a, with_mask, grid, st, tx);
+    else if (subpix == VSTAB_SUBPIX_EXACT) launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT>(a, with_mask, grid, st, tx);
+    else launch_mask<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5>(a, with_mask, grid, st, tx);
     VSTAB_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_warp_blur(const WarpArgs& a, int interp, int subpix, bool with_mask, hipStream_t st)
+{
+    if (interp == VSTAB_INTERP_BICUBIC) return launch_blur<VSTAB_INTERP_BICUBIC, VSTAB_SUBPIX_Q5>(a, with_mask, st);
+    if (subpix == VSTAB_SUBPIX_EXACT) return launch_blur<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_EXACT>(a, with_mask, st);
+    return launch_blur<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5>(a, with_mask, st);
 }
 
 void fill_xform(const float* m32, WarpXform* xf)
@@ -466,7 +750,7 @@ extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
     KernelTimer timer(ctx, "warp");
-    return launch_warp<false>(a, interp, subpix, mask != nullptr, ctx->stream);
+    return launch_warp(a, interp, subpix, mask != nullptr, ctx->stream);
 }
 
 // motion_apply.py:125-134 (_blurred_matrix_samples) + the f32 cast of motion_apply.py:172, for frames
@@ -521,7 +805,7 @@ extern "C" int vstab_warp_blur_clip_batch(vstab_ctx* ctx, const float* src, int 
     a.samples = samples; a.nxf_per_frame = per_frame;
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     KernelTimer timer(ctx, "warp_blur");
-    return launch_warp<true>(a, interp, subpix, mask != nullptr, ctx->stream);
+    return launch_warp_blur(a, interp, subpix, mask != nullptr, ctx->stream);
 }
 
 extern "C" int vstab_warp_blur_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w,

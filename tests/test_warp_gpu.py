@@ -253,3 +253,30 @@ def test_pipelined_upload_download_round_trip(ctx, nbytes):
     again = ctx.upload(host[: max(1, n // 3)])   # the ring is reused by a later call while nothing else synchronised
     assert torch.equal(again.cpu(), host[: max(1, n // 3)])
 
+
+
+@pytest.mark.parametrize("interp,samples", [("bilinear", 9), ("bicubic", 5), ("bicubic", 17), ("bilinear", 33)])
+@pytest.mark.parametrize("src,out,kind", [((270, 480), (270, 480), "similarity"),      # interior blocks + a border ring
+                                          ((270, 480), (300, 523), "similarity"),      # ragged last tile column / row
+                                          ((200, 333), (200, 333), "perspective"),     # perspective samples: general loop only
+                                          ((160, 400), (12, 400), "translation"),      # dh < 16: OpenCV column blocks of 85 px, not tile-aligned
+                                          ((128, 128), (128, 128), "identity")])
+def test_blur_interior_fast_path_matches_oracle(ctx, oracle, monkeypatch, interp, samples, src, out, kind):
+    """warp_blur_kernel classifies each tile once (all four corners, every sample, interior with margin) and runs the
+    interior tiles through a loop without bounds tests, with the weight PRODUCTS from the LDS table and block-origin
+    terms shared by a thread's two pixels; everything else takes the general loop.  Both must give the oracle's bits,
+    and the same bits as the general loop forced everywhere (VSTAB_BLUR_FAST=0)."""
+    n = 3
+    sh, sw = src
+    dh, dw = out
+    frames = synth_frames(n, sh, sw, seed=sh + samples)
+    mats = make_matrices(n, sw, sh, kind, seed=7)
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (dw, dh), 0.5, samples, interp=interp, border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (dw, dh), 0.5, samples, interp=interp, border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
+    monkeypatch.setenv("VSTAB_BLUR_FAST", "0")
+    dst0, mask0 = ctx.warp_blur_batch(frames, mats, (dw, dh), 0.5, samples, interp=interp, border=BORDER)
+    assert np.array_equal(dst0.cpu().numpy(), ref) and np.array_equal(mask0.cpu().numpy(), ref_mask)
+    # no mask requested: same pixels
+    dst1, mask1 = ctx.warp_blur_batch(frames, mats, (dw, dh), 0.5, samples, interp=interp, border=BORDER, want_mask=False)
+    assert mask1 is None and np.array_equal(dst1.cpu().numpy(), ref)
