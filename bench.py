@@ -14,6 +14,10 @@ Workloads (BASELINE.json configs):
          fit records): total work fixed -> "scaling": "strong".  `--total-frames T` picks another clip length (also at
          N = 1: `--gpus 1 --total-frames 1024` is the same clip on one GPU), `--frames F` fixes the frames per GPU
          instead ("weak").
+  --workload c5   BASELINE configs[4] as the timed step: one 512-frame 4K clip (64 frames = one GPU's share at N = 1), Flow
+         expand -> Motion Apply (expand, bilinear, motion_blur 0.5, Ultra = 33 samples) on the original frames, sharded
+         like C4 (the replay half has no collective).  At N > 1 the default run carries the same measurement as a
+         `c5` object on the C4 line (outside the timed loop), so a multi-GPU driver run reports both configs.
 N > 1 needs one process per GPU.  Started under torchrun (WORLD_SIZE set) this file is a rank; started plainly with
 --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before
 anything touches the GPU and relays its output (never an exec).
@@ -349,6 +353,88 @@ def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
     return out
 
 
+C5_FLOW_ARGS = ("expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+C5_APPLY = dict(framing_mode="expand", interpolation="bilinear", motion_blur=0.5, motion_blur_samples=33)
+
+
+def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, warmup) -> dict:
+    """BASELINE configs[4]: Flow (DIS, similarity) with expand framing, then Motion Apply (expand, bilinear, motion_blur
+    0.5, Ultra = 33 samples) on the ORIGINAL frames with the returned meta (call shapes: video_stabilizer_flow.py:734-763,
+    video_stabilizer_motion_apply.py:86-129), one `total`-frame clip sharded contiguously over the ranks.  The Flow half
+    has the one all-gather of fit records (+ the pad counts); the replay half has no collective (distributed.py).
+    Timed like the headline: barrier + synchronize on both sides, MAX over ranks."""
+    from vstab_amd import apply_pipeline as ap
+    from vstab_amd import distributed as vd
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    start, end = vd.shard_range(total, world, rank)
+    n_local = end - start
+    halo = 1 if (rank > 0 and n_local > 0) else 0
+    frames = synth_clip(n_local + halo, start - halo, h, w, device)
+    torch.cuda.synchronize()
+    stats: dict = {}
+    lap = {"flow": 0.0, "apply": 0.0}
+
+    def step():
+        t0 = time.perf_counter()
+        if use_dist:
+            _, _, meta = vd.stabilize_sharded(ctx, frames, total, *C5_FLOW_ARGS, stats=stats, want_meta=True)
+            t1 = time.perf_counter()
+            out = vd.apply_motion_sharded(ctx, frames[halo:], start, total, meta, (127, 127, 127), **C5_APPLY)
+        else:
+            res = fp._stabilize_frames(hm._normalize_video_input(frames), *C5_FLOW_ARGS, ctx=ctx, keep_on_device=True)
+            meta = res.meta
+            del res
+            t1 = time.perf_counter()
+            r = ap.apply_motion(hm._normalize_video_input(frames), meta, (127, 127, 127), ctx=ctx, keep_on_device=True, **C5_APPLY)
+            out = (r.frames, r.masks, r.meta)
+        lap["flow"] += t1 - t0
+        lap["apply"] += time.perf_counter() - t1
+        return out
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        out = step()
+        del out
+    fence()
+    ctx.set_timing(True)
+    stats.clear()
+    lap["flow"] = lap["apply"] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+        shape, ameta = list(out[0].shape), out[2]
+        del out
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_ms = {}
+    for kind in ("gray", "dis", "fit", "warp", "warp_blur"):
+        total_ms, launches = ctx.kernel_ms_stats(kind)
+        stage_ms[kind] = round(total_ms / max(launches, 1), 3)
+    del frames
+    torch.cuda.empty_cache()
+    out = {"workload": f"C5: one {total}-frame {w}x{h} clip, Flow (DIS) similarity + expand -> Motion Apply expand, bilinear, "
+                       "motion_blur 0.5, Ultra (33 samples) on the original frames, device-resident",
+           "value": round(total * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "total_frames": total,
+           "frames_per_gpu": n_local, "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "scaling": "strong", "out_shape_rank0": shape, "motion_blur_samples": ameta["motion_apply"]["motion_blur_samples"],
+           "rank0_stage_ms": stage_ms,
+           "rank0_host_ms": {"flow_half": round(lap["flow"] / steps * 1e3, 3), "apply_half_launch": round(lap["apply"] / steps * 1e3, 3),
+                             **{k: round(v / steps, 3) for k, v in stats.items()}},
+           "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo for the Flow half, RCCL all-gather "
+                       "of fit records; the Motion Apply half has no collective"}
+    return out
+
+
 def main() -> int:
     ap_ = argparse.ArgumentParser()
     ap_.add_argument("--gpus", type=int, default=1)
@@ -356,8 +442,12 @@ def main() -> int:
     ap_.add_argument("--warmup", type=int, default=2)
     ap_.add_argument("--frames", type=int, default=None, help="frames per GPU (weak scaling); default: C2 = 256 at N=1")
     ap_.add_argument("--total-frames", type=int, default=None, help="clip length sharded over all GPUs (strong scaling); default at N>1: C4 = 1024")
-    ap_.add_argument("--height", type=int, default=1080)
-    ap_.add_argument("--width", type=int, default=1920)
+    ap_.add_argument("--height", type=int, default=None, help="default 1080 (2160 for --workload c5)")
+    ap_.add_argument("--width", type=int, default=None, help="default 1920 (3840 for --workload c5)")
+    ap_.add_argument("--workload", choices=("auto", "c5"), default="auto",
+                     help="auto: C2 at N=1 / C4 at N>1 (the headline metric; at N>1 a C5 object rides on the same line). "
+                          "c5: time BASELINE configs[4] (512 x 4K Flow expand -> Motion Apply blur Ultra) as the line's value")
+    ap_.add_argument("--c5-frames", type=int, default=None, help="clip length of the C5 workload (default: 512 over N > 1 GPUs; 64 = one GPU's share of the 8-GPU config at N = 1)")
     ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
     ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
     ap_.add_argument("--no-extras", action="store_true", help="skip host_roundtrip / motion_apply (N=1 extras outside the timed loop)")
@@ -400,7 +490,21 @@ def main() -> int:
     ctx = native.Context(local_rank)
     ctx.set_timing(True)
 
-    h, w = args.height, args.width
+    if args.workload == "c5":
+        h, w = args.height or 2160, args.width or 3840
+        total5 = args.c5_frames or args.total_frames or (512 if world > 1 else 64)   # one GPU: the per-GPU share of the 8-GPU config
+        c5 = run_c5(ctx, torch, dist, device, rank, world, use_dist, total5, h, w, args.steps, args.warmup)
+        if rank == 0:
+            line = {"metric": "stabilized + motion-blurred frames/sec (4K, Flow expand -> Motion Apply Ultra; BASELINE configs[4])",
+                    "value": c5["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": c5["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic", "config": c5}
+            print(json.dumps(line), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return 0
+
+    h, w = args.height or 1080, args.width or 1920
     if args.frames is not None:
         total, scaling, label = args.frames * world, "weak", f"{args.frames} frames per GPU"
     elif args.total_frames is not None:
@@ -553,6 +657,18 @@ def main() -> int:
                     line["motion_apply"] = measure_motion_apply(ctx, torch, device)
                 except Exception as exc:  # the headline line must survive a failure of the extras
                     line["extras_error"] = f"{type(exc).__name__}: {exc}"
+    c5 = None
+    if world > 1 and not args.no_extras:
+        # BASELINE configs[4] on the same ranks, outside the timed loop above (every rank takes part: it has collectives)
+        del frames
+        torch.cuda.empty_cache()
+        try:
+            c5 = run_c5(ctx, torch, dist, device, rank, world, True, args.c5_frames or 512, 2160, 3840, max(2, args.steps // 2), 1)
+        except Exception as exc:   # all ranks fail alike (shape / memory), never one of them inside a collective
+            c5 = {"error": f"{type(exc).__name__}: {exc}"}
+    if rank == 0:
+        if c5 is not None:
+            line["c5"] = c5
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
