@@ -243,4 +243,77 @@ int vstab_host_math(int op, const double* a, const double* b, int n, double* out
     return 0;
 }
 
+// flow.py:340-346 for a whole clip in one call: _rescale_transform_to_full (stabilizer_utils.py:279-297: S^-1 M S in fp64,
+// stored as f32; S diagonal, so every entry is the product chain fl(fl(up_i * M_ij) * down_j)) followed by
+// _matrix_to_params (stabilizer_utils.py:300-324) on the f32 result -- its float32-scalar arithmetic (a*a + c*c, m00 - 1)
+// in f32, its math.* calls through this process's libm, as the per-item form does.
+int vstab_transitions_to_params(const float* work_mats, int count, int mode, const double* up, const double* down,
+                                float* full_mats, double* params)
+{
+    VSTAB_REQUIRE(count >= 0 && (count == 0 || (work_mats && full_mats && params)), "vstab_transitions_to_params: bad argument");
+    VSTAB_REQUIRE(mode >= VSTAB_MODE_TRANSLATION && mode <= VSTAB_MODE_PERSPECTIVE, "vstab_transitions_to_params: unknown mode %d", mode);
+    VSTAB_REQUIRE((up == nullptr) == (down == nullptr), "vstab_transitions_to_params: up and down come together");
+    for (int n = 0; n < count; n++) {
+        const float* M = work_mats + (size_t)n * 9;
+        float* F = full_mats + (size_t)n * 9;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                if (up) {
+                    const double t = up[i] * (double)M[i * 3 + j];
+                    F[i * 3 + j] = (float)(t * down[j]);
+                } else {
+                    F[i * 3 + j] = M[i * 3 + j];
+                }
+            }
+        if (mode == VSTAB_MODE_TRANSLATION) {
+            double* P = params + (size_t)n * 2;
+            P[0] = (double)F[2]; P[1] = (double)F[5];
+        } else if (mode == VSTAB_MODE_SIMILARITY) {
+            double* P = params + (size_t)n * 4;
+            const float a = F[0], c = F[3];
+            const float aa = a * a, cc = c * c;
+            const float sq = aa + cc;
+            const double sq64 = (1e-10f > sq) ? 1e-10 : (double)sq;
+            P[0] = (double)F[2]; P[1] = (double)F[5];
+            P[2] = std::atan2((double)c, (double)a);
+            P[3] = std::log(std::sqrt(sq64));
+        } else {
+            double* P = params + (size_t)n * 8;
+            const float d0 = F[0] - 1.0f, d4 = F[4] - 1.0f;
+            P[0] = (double)d0; P[1] = (double)F[1]; P[2] = (double)F[2]; P[3] = (double)F[3];
+            P[4] = (double)d4; P[5] = (double)F[5]; P[6] = (double)F[6]; P[7] = (double)F[7];
+        }
+    }
+    return 0;
+}
+
+// _params_to_matrix (stabilizer_utils.py:327-358) for a whole clip: fp64 arithmetic, f32 result.
+int vstab_params_to_matrices(const double* params, int count, int mode, float* mats)
+{
+    VSTAB_REQUIRE(count >= 0 && (count == 0 || (params && mats)), "vstab_params_to_matrices: bad argument");
+    VSTAB_REQUIRE(mode >= VSTAB_MODE_TRANSLATION && mode <= VSTAB_MODE_PERSPECTIVE, "vstab_params_to_matrices: unknown mode %d", mode);
+    for (int n = 0; n < count; n++) {
+        float* F = mats + (size_t)n * 9;
+        if (mode == VSTAB_MODE_TRANSLATION) {
+            const double* P = params + (size_t)n * 2;
+            F[0] = 1.f; F[1] = 0.f; F[2] = (float)P[0];
+            F[3] = 0.f; F[4] = 1.f; F[5] = (float)P[1];
+            F[6] = 0.f; F[7] = 0.f; F[8] = 1.f;
+        } else if (mode == VSTAB_MODE_SIMILARITY) {
+            const double* P = params + (size_t)n * 4;
+            const double s = std::exp(P[3]), ct = std::cos(P[2]), st = std::sin(P[2]);
+            const double sc = s * ct, ss = s * st;
+            F[0] = (float)sc; F[1] = (float)(-ss); F[2] = (float)P[0];
+            F[3] = (float)ss; F[4] = (float)sc; F[5] = (float)P[1];
+            F[6] = 0.f; F[7] = 0.f; F[8] = 1.f;
+        } else {
+            const double* P = params + (size_t)n * 8;
+            F[0] = (float)(P[0] + 1.0); F[1] = (float)P[1]; F[2] = (float)P[2];
+            F[3] = (float)P[3]; F[4] = (float)(P[4] + 1.0); F[5] = (float)P[5];
+            F[6] = (float)P[6]; F[7] = (float)P[7]; F[8] = 1.f;
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -240,10 +240,8 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
     base_mode = transform_mode
     working_size = hm._working_estimation_size(width, height)
     work_mats, modes_used, confidences, residuals, active_mode = select_transitions(fit_records, transform_mode)
-    matrices = np.asarray(work_mats, dtype=np.float32).reshape(-1, 3, 3)
-    if working_size is not None:
-        matrices = hm.rescale_transforms_to_full(matrices, size, working_size)
-    delta_params = hm.matrices_to_params(matrices, base_mode)
+    # rescale to full resolution + parameter deltas (flow.py:340-346), one library call over the clip
+    matrices, delta_params = native.transitions_to_params(work_mats, base_mode, size, working_size)
 
     # ---- trajectory (F7-F8) --------------------------------------------------
     strength = float(np.clip(strength, 0.0, 1.0))
@@ -305,7 +303,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         stabilization_scale = sol["scale"]
     else:
         crop_solution = None
-        apply_matrices = hm.params_to_matrices(diffs, base_mode)
+        apply_matrices = native.params_to_matrices(diffs, base_mode)
     output_size = size
     mins, maxs = hm.bounding_boxes_batched(apply_matrices, width, height)
     framing_meta: Dict[str, Any] = {

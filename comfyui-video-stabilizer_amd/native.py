@@ -146,6 +146,8 @@ _SIGNATURES = {
     "vstab_phase_correlate_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_host_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vstab_transitions_to_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vstab_params_to_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_crop_analysis": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_trajectory": (
@@ -196,6 +198,38 @@ def host_math(op: str, a, b=None) -> np.ndarray:
     bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
     rc = load_library().vstab_host_math(HOST_OPS[op], a.ctypes.data, bb.ctypes.data if bb is not None else None, a.size, out.ctypes.data)
     _check(rc, "vstab_host_math")
+    return out
+
+
+PARAM_COUNT = {"translation": 2, "similarity": 4, "perspective": 8}
+
+
+def transitions_to_params(work_mats, base_mode: str, source_size=None, working_size=None):
+    """flow.py:340-346 for a clip (vstab_transitions_to_params): f32 [P,3,3] at working resolution ->
+    (f32 [P,3,3] at full resolution, f64 [P,K] parameter deltas).  working_size None: estimated at full size."""
+    m = np.ascontiguousarray(work_mats, dtype=np.float32).reshape(-1, 9)
+    count = m.shape[0]
+    full = np.empty((count, 9), np.float32)
+    params = np.empty((count, PARAM_COUNT[base_mode]), np.float64)
+    if working_size is not None:
+        sx = working_size[0] / float(source_size[0])
+        sy = working_size[1] / float(source_size[1])
+        up = np.array([1.0 / sx, 1.0 / sy, 1.0], np.float64)
+        down = np.array([sx, sy, 1.0], np.float64)
+        up_p, down_p = up.ctypes.data, down.ctypes.data
+    else:
+        up_p = down_p = None
+    _check(load_library().vstab_transitions_to_params(m.ctypes.data, count, MODES[base_mode], up_p, down_p, full.ctypes.data,
+                                                      params.ctypes.data), "vstab_transitions_to_params")
+    return full.reshape(count, 3, 3), params
+
+
+def params_to_matrices(params, base_mode: str) -> np.ndarray:
+    """_params_to_matrix for a clip (vstab_params_to_matrices): f64 [N,K] -> f32 [N,3,3]."""
+    p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, PARAM_COUNT[base_mode])
+    out = np.empty((p.shape[0], 3, 3), np.float32)
+    _check(load_library().vstab_params_to_matrices(p.ctypes.data, p.shape[0], MODES[base_mode], out.ctypes.data),
+           "vstab_params_to_matrices")
     return out
 
 

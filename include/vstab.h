@@ -278,6 +278,21 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
 enum { VSTAB_HOST_SQRT = 0, VSTAB_HOST_ATAN2 = 1, VSTAB_HOST_LOG = 2, VSTAB_HOST_EXP = 3, VSTAB_HOST_COS = 4, VSTAB_HOST_SIN = 5 };
 int vstab_host_math(int op, const double* a, const double* b, int n, double* out);
 
+/* ---- F6 / F9 for a whole clip (host pointers, no GPU involved) ----
+ * vstab_transitions_to_params: nodes/video_stabilizer_flow.py:340-346 per transition --
+ *   _rescale_transform_to_full (stabilizer_utils.py:279-297; skipped when up == down == NULL: estimated at full size)
+ *   then _matrix_to_params (stabilizer_utils.py:300-324) of the requested mode.
+ *   work_mats host [count,9] f32 (working resolution); up = {1/sx, 1/sy, 1}, down = {sx, sy, 1} with
+ *   sx = working_w / source_w, sy = working_h / source_h (fp64, as the reference forms them);
+ *   full_mats host [count,9] f32; params host [count, 2 | 4 | 8] f64.
+ * vstab_params_to_matrices: _params_to_matrix (stabilizer_utils.py:327-358): params host [count, 2|4|8] f64 ->
+ *   mats host [count,9] f32.  mode = VSTAB_MODE_*.
+ * Replicated on every rank of a multi-GPU run for the whole clip (the serial part of a rank's step): one call each
+ * instead of ~25 NumPy / ctypes calls.  Same libm, same rounding points as the per-item Python forms. */
+int vstab_transitions_to_params(const float* work_mats, int count, int mode, const double* up, const double* down,
+                                float* full_mats, double* params);
+int vstab_params_to_matrices(const double* params, int count, int mode, float* mats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -429,3 +429,35 @@ def test_node_schema_contents_match_reference(pkg):
                             d[enum_key] = str(d[enum_key]).split(".")[-1]
                 assert declared == expected, (where, declared, expected)
     assert seen == set(golden)
+
+
+@pytest.mark.parametrize("mode", ["translation", "similarity", "perspective"])
+def test_clip_parameter_maps_equal_the_per_item_forms(pkg, mode):
+    """vstab_transitions_to_params / vstab_params_to_matrices (host only) against the per-item restatements of
+    stabilizer_utils.py:279-358 (`_rescale_transform_to_full`, `_matrix_to_params`, `_params_to_matrix`, themselves pinned
+    bit for bit by the reference-run goldens of tests/test_host_golden.py) and against the vectorised NumPy forms: same
+    bits, with and without the working-size rescale, incl. degenerate matrices (zero 2x2 part: the 1e-10 floor)."""
+    from vstab_amd import host_math as hm
+    from vstab_amd import native
+
+    rng = np.random.default_rng(11)
+    n = 300
+    mats = np.tile(np.eye(3, dtype=np.float32), (n, 1, 1))
+    mats[:, :2, :2] += rng.normal(0, 0.05, (n, 2, 2)).astype(np.float32)
+    mats[:, :2, 2] = rng.normal(0, 20, (n, 2)).astype(np.float32)
+    if mode == "perspective":
+        mats[:, 2, :2] = rng.normal(0, 1e-4, (n, 2)).astype(np.float32)
+    mats[0, :2, :2] = 0.0          # a*a + c*c below the floor
+    mats[1, 0, 0], mats[1, 1, 0] = -1.0, 0.0   # atan2 at pi
+    for size, work in (((1920, 1080), (960, 540)), ((1000, 777), (960, 746)), ((480, 270), None)):
+        full, params = native.transitions_to_params(mats, mode, size, work)
+        want_full = np.stack([hm._rescale_transform_to_full(m, size, work) if work else m for m in mats])
+        assert full.dtype == np.float32 and np.array_equal(full, want_full)
+        want_params = np.stack([hm._matrix_to_params(m, mode) for m in want_full])
+        assert params.dtype == np.float64 and np.array_equal(params, want_params)
+        assert np.array_equal(params, hm.matrices_to_params(hm.rescale_transforms_to_full(mats, size, work) if work else mats, mode))
+    p = rng.normal(0, 1.0, (n, native.PARAM_COUNT[mode])) * (0.05 if mode != "translation" else 30.0)
+    got = native.params_to_matrices(p, mode)
+    want = np.stack([hm._params_to_matrix(row, mode) for row in p])
+    assert got.dtype == np.float32 and np.array_equal(got, want) and np.array_equal(got, hm.params_to_matrices(p, mode))
+    assert native.params_to_matrices(np.zeros((0, native.PARAM_COUNT[mode])), mode).shape == (0, 3, 3)
