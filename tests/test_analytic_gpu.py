@@ -17,7 +17,8 @@ tools/analytic_accuracy.py (profiles/r03_analytic_accuracy.md); each is the meas
   portrait 540x960: the clip's texture scales with the frame width (x 3.6 in frequency against 1920: 16 px wavelength),
       closer to what an 8 px patch can resolve -- a property of the clip, not of the estimator
       centre <= 0.13 px (0.093), corner <= 0.16 px (0.120), 2x2 <= 2.5e-4 (1.7e-4)
-  perspective: see PERSPECTIVE_BOUNDS below (the homography has 8 degrees of freedom to spend on DIS's border bias)
+  perspective: see PERSPECTIVE_BOUNDS below (centre <= 0.08 px, worst corner <= 0.25 px: the homography has 8 degrees of
+      freedom to spend on DIS's border bias; its 2x2 entries are not separately identifiable)
 
 The previous gates (test_nodes_gpu.py: 0.8 px / 3e-3, translation mode 2.5 px / 2e-2) are replaced by these.
 """
@@ -40,7 +41,7 @@ BOUNDS = {
 }
 # perspective: displacement only -- the entries of a homography's 2x2 part trade against its perspective row times the
 # translation (H00 = a + tx * p0), so they are not separately identifiable to 1e-4 while the mapping itself is
-PERSPECTIVE_BOUNDS = {"landscape": (0.08, 0.16, 1.0), "portrait": (0.16, 0.3, 1.0)}
+PERSPECTIVE_BOUNDS = {"landscape": (0.08, 0.25, 1.0), "portrait": (0.16, 0.30, 1.0)}   # measured max (48 pairs): 0.026 / 0.170, 0.076 / 0.199
 
 
 @pytest.fixture(scope="module")
