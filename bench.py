@@ -579,13 +579,13 @@ def main() -> int:
             "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo, RCCL all-gather of fit records",
             "stage_ms": {k: round(float(v), 3) for k, v in stage_ms.items()},
         }
-        ref = ROOT / "profiles" / "r02_c4_single_gpu.json"
+        ref = ROOT / "profiles" / "r03_c4_single_gpu.json"
         if world > 1 and scaling == "strong" and ref.exists():
             rj = json.loads(ref.read_text())
             if rj.get("total_frames") == total and rj.get("size") == [w, h]:
                 # the denominator of a strong-scaling ratio is the SAME clip on one GPU, not the N=1 default (C2, 256 frames)
                 config["same_clip_on_one_gpu"] = {"frames_per_s": rj["frames_per_s"], "ms_per_step": rj["ms_per_step"],
-                                                  "source": "profiles/r02_c4_single_gpu.json (static: `bench.py --gpus 1 --total-frames "
+                                                  "source": "profiles/r03_c4_single_gpu.json (static: `bench.py --gpus 1 --total-frames "
                                                             f"{total}` on one MI355X, not measured in this run)"}
         if use_dist:
             config["rank0_host_ms"] = {k: round(v / args.steps, 3) for k, v in stats.items()}
