@@ -195,6 +195,9 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     t0 = _lap(stats, "plan", t0)
     own = local_frames[halo:]
     if plan.bypass_meta is not None:   # crop + keep_fov ~ 1 (flow.py:387-429): the original frames, zero masks
+        # Returning BEFORE the second collective is safe only because the decision is replicated: `plan` is a pure function
+        # of the gathered records and the call's arguments (keep_fov, framing_mode), identical on every rank, so either
+        # all ranks return here or none does -- no rank is left waiting in the pad-count all-gather.
         masks = torch.zeros((n_local, height, width), dtype=torch.float32, device=own.device)
         return own, masks, _attach_motion_meta(plan.bypass_meta, fps_effective, estimator)
     out_w, out_h = plan.output_size
