@@ -658,12 +658,14 @@ def main() -> int:
                 except Exception as exc:  # the headline line must survive a failure of the extras
                     line["extras_error"] = f"{type(exc).__name__}: {exc}"
     c5 = None
-    if world > 1 and not args.no_extras:
-        # BASELINE configs[4] on the same ranks, outside the timed loop above (every rank takes part: it has collectives)
+    if use_dist and not args.no_extras:
+        # BASELINE configs[4] on the same ranks, outside the timed loop above (every rank takes part: it has collectives).
+        # `--gpus 1 --force-dist` rehearses exactly this path on one GPU's share of the clip.
         del frames
         torch.cuda.empty_cache()
         try:
-            c5 = run_c5(ctx, torch, dist, device, rank, world, True, args.c5_frames or 512, 2160, 3840, max(2, args.steps // 2), 1)
+            c5 = run_c5(ctx, torch, dist, device, rank, world, True, args.c5_frames or (512 if world > 1 else 64), 2160, 3840,
+                        max(2, args.steps // 2), 1)
         except Exception as exc:   # all ranks fail alike (shape / memory), never one of them inside a collective
             c5 = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:

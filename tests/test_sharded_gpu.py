@@ -197,3 +197,75 @@ def test_sharded_motion_apply_equals_single_process(pkg, ctx, framing, interp, b
     assert f.shape[0] == 0 and tuple(f.shape[1:]) == ref.frames.shape[1:] and json.loads(json.dumps(rmeta)) == json.loads(json.dumps(ref.meta))
     with pytest.raises(ValueError, match="Frame count mismatch"):
         vd.apply_motion_sharded(ctx, torch.from_numpy(frames[:3]).cuda(), 0, n + 1, meta, (10, 200, 30), **kw)
+
+
+def _c4_worker(rank, world, port, out_dir, total, h, w):
+    """One rank of the C4-sized run: synthesises ITS shard of the bench clip on the GPU (halo frame included), runs the
+    sharded Flow pipeline, leaves per-frame bit checksums, three whole frames and the meta behind."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    import bench
+    from vstab_amd import distributed as vd
+    from vstab_amd import native
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = native.Context(0)
+        start, end = vd.shard_range(total, world, rank)
+        halo = 1 if rank > 0 else 0
+        local = bench.synth_clip(end - start + halo, start - halo, h, w, torch.device("cuda", 0))
+        dst, mask, meta = vd.stabilize_sharded(ctx, local, total, *bench.FLOW_ARGS)
+        torch.save({"dst": _frame_checksums(dst), "mask": _frame_checksums(mask), "start": start,
+                    "frames": {i: dst[i - start].cpu() for i in (start, (start + end) // 2, end - 1)}},
+                   Path(out_dir) / f"c4_{rank}.pt")
+        if rank == 0:
+            (Path(out_dir) / "c4_meta.json").write_text(json.dumps(meta))
+    finally:
+        dist.destroy_process_group()
+
+
+def _frame_checksums(t):
+    """Order-independent exact checksum per frame: the float bit patterns summed as int64."""
+    import torch
+
+    return t.contiguous().view(torch.int32).reshape(t.shape[0], -1).to(torch.int64).sum(dim=1).cpu()
+
+
+def test_c4_sized_clip_two_ranks_equal_single_process(pkg, ctx, tmp_path):
+    """BASELINE configs[3] at its SIZE: one 1024-frame 1080p clip, Flow similarity + crop_and_pad,
+    sharded over two ranks (both on this box's one GPU, gloo control plane -- RCCL refuses two ranks on a device), against
+    the single-process pipeline on the same 1024 frames: per-frame bit checksums of every output frame and mask, three
+    whole frames per rank and the whole meta (plan over 1023 transitions, halo pair at frame 512) must be equal.  The
+    single-process path is the one checked against the oracle at 256 frames (tests/test_configs_gpu.py)."""
+    import torch
+    import torch.multiprocessing as mp
+
+    import bench
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    total, h, w = 1024, 1080, 1920
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_c4_worker, args=(2, port, str(tmp_path), total, h, w), nprocs=2, join=True)
+    frames = bench.synth_clip(total, 0, h, w, torch.device("cuda", 0))
+    res = fp._stabilize_frames(hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
+    del frames
+    want_dst, want_mask = _frame_checksums(res.frames), _frame_checksums(res.masks)
+    parts = [torch.load(tmp_path / f"c4_{r}.pt") for r in range(2)]
+    assert [p["start"] for p in parts] == [0, 512]
+    assert torch.equal(torch.cat([p["dst"] for p in parts]), want_dst)
+    assert torch.equal(torch.cat([p["mask"] for p in parts]), want_mask)
+    for p in parts:
+        for i, f in p["frames"].items():
+            assert torch.equal(f, res.frames[i].cpu()), i
+    assert json.loads((tmp_path / "c4_meta.json").read_text()) == json.loads(json.dumps(res.meta))
+    assert res.meta["frames"] == total and len(res.meta["estimated_motion"]["per_transition"]) == total - 1
