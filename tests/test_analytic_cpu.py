@@ -1,0 +1,71 @@
+"""The CPU suite's share of the oracle-independent evidence (the GPU half: tests/test_analytic_gpu.py).
+
+The oracle's estimation chain (gray -> DIS -> stride-8 sampling -> model fit: the restatement of cv2.cvtColor / resize,
+cv2.DISOpticalFlow, cv2.estimateAffinePartial2D / findHomography that nothing reference-held can pin) must recover the
+known motion of analytic clips -- clips whose every pixel is a closed-form function of a known camera path, so the true
+transition of every pair is known exactly.  The HIP path equals the oracle bit for bit (tests/test_dis_gpu.py,
+tests/test_fit_gpu.py), so what is shown here for the checker holds for the product.  The clips are 960x540 (the working size of every BASELINE config; bench.synth_clip scales its texture with the frame
+width, so smaller frames would be a harder clip, not a faster test); bounds as in the GPU file."""
+
+import numpy as np
+import pytest
+
+from tests.util import shake_path
+
+
+def _clip(n, w, h, kind, amp, seed=3):
+    import torch
+
+    import bench
+
+    cam = shake_path(n, w, h, kind, seed=seed, amp=amp)
+    frames = bench.synth_clip(n, 0, h, w, torch.device("cpu"), mats=cam).numpy()
+    return cam, frames
+
+
+def test_transition_accuracy_metric_is_zero_for_the_truth_and_scales_with_resolution():
+    import bench
+
+    cam = shake_path(6, 1920, 1080, "perspective", amp=2.0)
+    truth = [cam[i + 1] @ np.linalg.inv(cam[i]) for i in range(5)]
+    acc = bench.transition_accuracy([m / m[2, 2] for m in truth], cam, (1920, 1080), (960, 540))
+    assert acc["centre_px"]["max"] < 1e-9 and acc["corner_px"]["max"] < 1e-9 and acc["lin_2x2"]["max"] < 1e-12
+    off = [np.array([[1, 0, 0.2], [0, 1, 0], [0, 0, 1.0]]) @ m for m in truth]     # 0.2 full-res px = 0.1 working px
+    acc = bench.transition_accuracy(off, cam, (1920, 1080), (960, 540))
+    assert abs(acc["centre_px"]["max"] - 0.1) < 1e-6 and abs(acc["corner_px"]["mean"] - 0.1) < 1e-3
+
+
+@pytest.mark.parametrize("kind,amp,centre,corner,lin", [("translation", 1.0, 0.05, 0.05, 1e-12), ("similarity", 1.0, 0.05, 0.09, 2e-4),
+                                                        ("perspective", 1.0, 0.06, 0.2, 1.0), ("similarity", 3.0, 0.05, 0.09, 2e-4)])
+def test_oracle_recovers_known_camera_motion(oracle, pkg, kind, amp, centre, corner, lin):
+    import bench
+    from vstab_amd import flow_pipeline as fp
+
+    w, h, n = 960, 540, 4
+    cam, frames = _clip(n, w, h, kind, amp)
+    gray = oracle.gray_for_estimation(frames, None)
+    flow = oracle.dis_flow_clip(gray)
+    recs = [oracle.fit_all_modes(flow[i], 8, kind)[0] for i in range(n - 1)]
+    mats, modes, _, _, _ = fp.select_transitions(recs, kind)
+    assert modes == [kind] * (n - 1)
+    acc = bench.transition_accuracy(mats, cam, (w, h), None)
+    assert acc["true_motion_px"]["max"] > 0.5
+    assert acc["centre_px"]["max"] <= centre and acc["corner_px"]["max"] <= corner and acc["lin_2x2"]["max"] <= lin, acc
+
+
+def test_homography_fit_alone_is_exact_on_an_analytic_flow_field(oracle):
+    """The fit without DIS: a flow field computed in closed form from a known homography (plus bounded noise) must give
+    that homography back -- 1e-9 px without noise, a few thousandths of a pixel with 0.05 px of noise."""
+    h, w = 270, 480
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    H = np.array([[1.002, -0.003, 3.2], [0.003, 1.002, -1.7], [4e-6, -2e-6, 1.0]])
+    den = H[2, 0] * xx + H[2, 1] * yy + 1.0
+    exact = np.stack([(H[0, 0] * xx + H[0, 1] * yy + H[0, 2]) / den - xx, (H[1, 0] * xx + H[1, 1] * yy + H[1, 2]) / den - yy], -1)
+    pts = np.array([[0, 0, 1.0], [w - 1, 0, 1], [0, h - 1, 1], [w - 1, h - 1, 1], [w / 2, h / 2, 1]]).T
+    want = (H @ pts)[:2] / (H @ pts)[2]
+    for noise, bound in ((0.0, 1e-4), (0.05, 0.02)):
+        flow = (exact + np.random.default_rng(1).normal(0, noise, exact.shape)).astype(np.float32)
+        out, _, _ = oracle.fit_all_modes(flow, 8, "perspective")
+        m = out["perspective"]["matrix"].astype(np.float64)
+        got = (m @ pts)[:2] / (m @ pts)[2]
+        assert out["perspective"]["accepted"] and np.hypot(*(got - want)).max() < bound, (noise, np.hypot(*(got - want)).max())
