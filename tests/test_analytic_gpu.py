@@ -112,3 +112,34 @@ def test_locked_camera_shows_the_static_texture(api, ctx, size, mode):
     raw = Raw()
     raw.frames, raw.masks, raw.meta = frames, torch.zeros_like(res.masks), {"framing": {"center_offset": [0.0, 0.0]}}
     assert bench.static_texture_error(raw, cam, frames, torch.device("cuda"))["psnr_db"] < 30.0
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("blur_samples", [0, 9])
+def test_warp_reproduces_an_analytic_texture(ctx, interp, blur_samples):
+    """warpPerspective's conventions without OpenCV or the oracle: warping frame(p) = T(p) by M must give T(M^-1 p) up to
+    the interpolation error of the band-limited texture and the 1/32-px coordinate quantisation (1080p: measured max
+    2-3e-3, mean 3-7e-4; a half-pixel convention error would be ~0.03, a transposed / inverted matrix far more).  M has
+    sub-pixel translation, rotation, zoom and perspective.  With blur_samples the same matrix is given to every frame,
+    so the S-sample motion blur (staged-window kernel) must reproduce the plain result."""
+    import torch
+
+    import bench
+
+    w, h, n = 1920, 1080, 2
+    dev = torch.device("cuda")
+    src = bench.synth_clip(1, 0, h, w, dev, mats=np.eye(3)[None], seed=7).expand(n, h, w, 3).contiguous()
+    m = np.array([[1.01 * np.cos(0.02), -1.01 * np.sin(0.02), 13.37], [1.01 * np.sin(0.02), 1.01 * np.cos(0.02), -9.61], [5e-6, -2.5e-6, 1.0]])
+    want = bench.synth_clip(1, 0, h, w, dev, mats=m[None], seed=7)[0]
+    mats = np.tile(m[None], (n, 1, 1))
+    if blur_samples:
+        got, mask = ctx.warp_blur_batch(src, mats, (w, h), 0.5, blur_samples, interp=interp, border=(0.5, 0.5, 0.5))
+    else:
+        got, mask, _ = ctx.warp_batch(src, mats.astype(np.float32), (w, h), interp=interp, border=(0.5, 0.5, 0.5))
+    inside = (mask[0] == 0)
+    inside = ~(torch.nn.functional.max_pool2d((~inside)[None, None].float(), 9, stride=1, padding=4)[0, 0] > 0)
+    inside[:4] = inside[-4:] = False
+    inside[:, :4] = inside[:, -4:] = False
+    err = (got[0] - want).abs().amax(dim=-1)
+    assert float(inside.float().mean()) > 0.9
+    assert float(err[inside].max()) < 6e-3 and float(err[inside].mean()) < 1.5e-3, (float(err[inside].max()), float(err[inside].mean()))
