@@ -856,12 +856,20 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     const float* __restrict__ U = Uw;
     const float* __restrict__ V = Vw;
     // the pixels of this workgroup: all of the pair's (fused), or every nparts-th block of FUSED_T (split)
+    // (x, y) of a thread's pixels advance incrementally: one integer division per phase instead of one per pixel (a
+    // runtime divisor costs ~25 instructions; the per-pixel phases have 50-100)
+    const int px_stride_ = nparts * (int)blockDim.x;
+    const int px_dy_ = px_stride_ / w, px_dx_ = px_stride_ - px_dy_ * w;
 #define FOR_PX(...)                                                                                   \
-    for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {   \
-        const int y = q_ / w, x = q_ - y * w;                                                         \
-        const int t = q_;                                                                             \
-        (void)x; (void)y;                                                                             \
-        __VA_ARGS__;                                                                                  \
+    {                                                                                                 \
+        int q_ = part * (int)blockDim.x + (int)threadIdx.x;                                           \
+        int y = q_ / w, x = q_ - y * w;                                                               \
+        for (; q_ < npx; q_ += px_stride_) {                                                          \
+            const int t = q_;                                                                         \
+            __VA_ARGS__;                                                                              \
+            x += px_dx_; y += px_dy_;                                                                 \
+            if (x >= w) { x -= w; y++; }                                                              \
+        }                                                                                             \
     }                                                                                                 \
     if (FUSED) __syncthreads();
     if (FUSED || MODE == LEVEL_PRE) {
@@ -926,8 +934,9 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             const int rs2 = 2 * hw;                   // LDS distance of vertical neighbours
 #define LIDX(py_, px_) ((2 * (py_) + ((px_) & 1)) * hw + ((px_) >> 1))
             // ---- stage 1: zero border, load the increment, compute the smoothness weights into LDS
+            const int s1_dy = (int)blockDim.x / pw, s1_dx = (int)blockDim.x - s1_dy * pw;
+            int py = (int)threadIdx.x / pw, px = (int)threadIdx.x - py * pw;
             for (int k = threadIdx.x; k < pn; k += blockDim.x) {
-                const int py = k / pw, px = k - py * pw;
                 const int lx = px - 1, ly = py - 1;
                 float wv = 0.f, du = 0.f, dv = 0.f;
                 if (lx >= 0 && lx < lw && ly >= 0 && ly < lh) {
@@ -943,6 +952,8 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                     wv = div_plain(a.alpha2, sqrt_plain(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
                 }
                 lP[LIDX(py, px)] = f4_t{du, dv, wv, 0.f};
+                px += s1_dx; py += s1_dy;
+                if (px >= pw) { px -= pw; py++; }
             }
             __syncthreads();
             FUSED_MARK(3);
@@ -1083,13 +1094,16 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             FUSED_MARK(5);
             // ---- stage 4: write the tile interior of the new increment
             const int iw = ix1 - ix0, ih = iy1 - iy0;
+            const int s4_dy = (int)blockDim.x / iw, s4_dx = (int)blockDim.x - s4_dy * iw;
+            int yy = (int)threadIdx.x / iw, xx = (int)threadIdx.x - yy * iw;
             for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
-                const int yy = k / iw, xx = k - yy * iw;
                 const int gx = ix0 + xx, gy = iy0 + yy;
                 const int li = LIDX(gy - oy + 1, gx - ox + 1);
                 const f2_t uv = *reinterpret_cast<const f2_t*>(lP + li);
                 dOut_u[gy * w + gx] = uv.x;
                 dOut_v[gy * w + gx] = uv.y;
+                xx += s4_dx; yy += s4_dy;
+                if (xx >= iw) { xx -= iw; yy++; }
             }
             __syncthreads();
             FUSED_MARK(6);
@@ -1114,9 +1128,13 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
         const int nn = a.nh * a.nw;
         float* __restrict__ nU = a.nextU + (long long)pair * nn;
         float* __restrict__ nV = a.nextV + (long long)pair * nn;
-        for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < nn; q_ += nparts * (int)blockDim.x) {
-            const int dy = q_ / a.nw, dx = q_ - dy * a.nw;
+        const int up_dy = px_stride_ / a.nw, up_dx = px_stride_ - up_dy * a.nw;
+        int q_ = part * (int)blockDim.x + (int)threadIdx.x;
+        int dy = q_ / a.nw, dx = q_ - dy * a.nw;
+        for (; q_ < nn; q_ += px_stride_) {
             upsample_px(U, V, nU, nV, q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
+            dx += up_dx; dy += up_dy;
+            if (dx >= a.nw) { dx -= a.nw; dy++; }
         }
     }
 #ifdef VSTAB_FUSED_TRACE

@@ -280,3 +280,16 @@ def test_blur_interior_fast_path_matches_oracle(ctx, oracle, monkeypatch, interp
     # no mask requested: same pixels
     dst1, mask1 = ctx.warp_blur_batch(frames, mats, (dw, dh), 0.5, samples, interp=interp, border=BORDER, want_mask=False)
     assert mask1 is None and np.array_equal(dst1.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "bicubic"])
+def test_blur_single_frame_quirk_on_the_staged_path(ctx, oracle, interp):
+    """motion_apply.py:125-127,195 on an interior tile: a 1-frame clip yields ONE sample matrix but is still divided by S,
+    for the pixels and for the coverage alike (mask = 1 - 1/S) -- the staged-window loop must keep that quirk."""
+    frames = synth_frames(1, 160, 200, seed=8)
+    mats = make_matrices(1, 200, 160, "similarity", seed=2)
+    mats[0, :2, 2] *= 0.2
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (200, 160), 0.5, 9, interp=interp, border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (200, 160), 0.5, 9, interp=interp, border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
+    assert abs(float(ref_mask[0, 80, 100]) - (1.0 - 1.0 / 9.0)) < 1e-6
