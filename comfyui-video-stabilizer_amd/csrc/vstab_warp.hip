@@ -543,6 +543,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                         else { sr += tr_; sg += tg_; sb += tb_; }
                     }
                     acc[p][0] += sr; acc[p][1] += sg; acc[p][2] += sb;
+                    __builtin_amdgcn_sched_barrier(0);   // one pixel's 16 taps at a time: both in flight need > 128 VGPRs (spills)
                 } else {
                     const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
                     const f4_t w = reinterpret_cast<const f4_t*>(s_tab)[fy * 32 + fx];

@@ -12,7 +12,7 @@ done
 python3 - <<PY
 import csv, glob, re, collections
 def short(name):
-    m = re.search(r"(level_kernel<\d+>|pis4_kernel<\d+>|warp_kernel<[^>]*>|gray_area_int_kernel<[^>]*>|fit_kernel|area_u8_kernel|area_general_rows_kernel)", name)
+    m = re.search(r"(level_kernel<\d+>|pis4_kernel<\d+>|warp_(?:blur_)?kernel<[^>]*>|gray_area_int_kernel<[^>]*>|fit_kernel|area_u8_kernel|area_general_rows_kernel)", name)
     return m.group(1).replace(", ", ",") if m else None
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
