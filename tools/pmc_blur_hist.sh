@@ -3,6 +3,10 @@
 # issues, by class), per pixel-sample.  Bounded passes, --pmc with --kernel-trace only, program directly after `--`.
 #   usage: tools/pmc_blur_hist.sh <tag>   -> gpurun_out/<tag>_blur_hist.md
 cd /tmp && export TMPDIR=/tmp
+# one HIP stream under counter collection: the profiler serialises dispatches, and a kernel queued behind an event of the
+# library's second (preparation) stream can then wait for a kernel the serialiser holds back -- a pass that hangs after
+# "[pmc_target] clip ready" (profiles/r03_pmc_stuck_pass.md)
+export VSTAB_DIS_PREP_STREAM=0
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
 OUT=$R/gpurun_out/pmc_blur_$TAG; rm -rf $OUT /tmp/pmc_blur_*; mkdir -p $OUT

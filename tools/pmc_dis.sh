@@ -3,6 +3,10 @@
 # --pmc with --kernel-trace only (no other trace domain), program directly after `--`.
 #   usage: tools/pmc_dis.sh <tag>      -> gpurun_out/<tag>_pmc_kernels.csv (+ the raw per-dispatch csv of each pass)
 cd /tmp && export TMPDIR=/tmp
+# one HIP stream under counter collection: the profiler serialises dispatches, and a kernel queued behind an event of the
+# library's second (preparation) stream can then wait for a kernel the serialiser holds back -- a pass that hangs after
+# "[pmc_target] clip ready" (profiles/r03_pmc_stuck_pass.md)
+export VSTAB_DIS_PREP_STREAM=0
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
 OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT /tmp/pmc_dis_*; mkdir -p $OUT

@@ -3,6 +3,10 @@
 # WRITE_SIZE do not fit one pass), --pmc with --kernel-trace only, program directly after `--`.
 #   usage: tools/pmc_traffic.sh <tag>   -> gpurun_out/<tag>_hbm_traffic.csv (per-dispatch means, KB as the counters report)
 cd /tmp && export TMPDIR=/tmp
+# one HIP stream under counter collection: the profiler serialises dispatches, and a kernel queued behind an event of the
+# library's second (preparation) stream can then wait for a kernel the serialiser holds back -- a pass that hangs after
+# "[pmc_target] clip ready" (profiles/r03_pmc_stuck_pass.md)
+export VSTAB_DIS_PREP_STREAM=0
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
 OUT=$R/gpurun_out/pmc_traffic_$TAG; rm -rf $OUT; mkdir -p $OUT

@@ -1,6 +1,10 @@
 #!/bin/bash
 # PMC counters of the warp kernel (microbench, 64 frames), one bounded rocprofv3 pass per group.
 cd /tmp && export TMPDIR=/tmp
+# one HIP stream under counter collection: the profiler serialises dispatches, and a kernel queued behind an event of the
+# library's second (preparation) stream can then wait for a kernel the serialiser holds back -- a pass that hangs after
+# "[pmc_target] clip ready" (profiles/r03_pmc_stuck_pass.md)
+export VSTAB_DIS_PREP_STREAM=0
 R=$GRAFT_REPO_ROOT
 OUT=/tmp/pmc_warp; rm -rf $OUT; mkdir -p $OUT
 i=0
