@@ -11,6 +11,15 @@ import bench
 from vstab_amd import apply_pipeline as ap, host_math as hm, native
 
 ctx = native.Context(0)
+
+
+def _settled(t):
+    """Input context with the value-range sniff settled up front: Motion Apply then stays on ONE stream (its optimistic sniff
+    would run on a side stream; under counter collection cross-stream waits can deadlock, profiles/r03_pmc_stuck_pass.md)."""
+    c = hm._normalize_video_input(t)
+    hm.resolve_value_range(c)
+    return c
+
 for fixture, n, h, w, framing, interp, samples in (("shake_c3_256x1080p.json", 32, 1080, 1920, "crop_and_pad", "bicubic", 17),
                                                    ("shake_c5_64x4k.json", 8, 2160, 3840, "expand", "bilinear", 33)):
     meta = {"motion_meta": json.loads((ROOT / "tests" / "golden" / fixture).read_text())}
@@ -19,7 +28,7 @@ for fixture, n, h, w, framing, interp, samples in (("shake_c3_256x1080p.json", 3
     blk["frame_count"] = n
     frames = bench.synth_clip(n, 0, h, w, torch.device("cuda", 0))
     for _ in range(2):
-        r = ap.apply_motion(hm._normalize_video_input(frames), meta, (127, 127, 127), framing_mode=framing, interpolation=interp,
+        r = ap.apply_motion(_settled(frames), meta, (127, 127, 127), framing_mode=framing, interpolation=interp,
                             motion_blur=0.5, motion_blur_samples=samples, ctx=ctx, keep_on_device=True)
         shape = tuple(r.frames.shape)
         del r

@@ -16,6 +16,15 @@ def say(msg):
 
 
 ctx = native.Context(0)
+
+
+def _settled(t):
+    """Input context with the value-range sniff settled up front: Motion Apply then stays on ONE stream (its optimistic sniff
+    would run on a side stream; under counter collection cross-stream waits can deadlock, profiles/r03_pmc_stuck_pass.md)."""
+    c = hm._normalize_video_input(t)
+    hm.resolve_value_range(c)
+    return c
+
 frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
 say("clip ready")
 for k in range(2):
@@ -27,7 +36,7 @@ meta = {"motion_meta": json.loads((ROOT / "tests" / "golden" / "shake_c3_256x108
 blk = meta["motion_meta"]
 blk["per_frame"] = blk["per_frame"][:64]
 blk["frame_count"] = 64
-r = ap.apply_motion(hm._normalize_video_input(frames[:64]), meta, (127, 127, 127), framing_mode="crop_and_pad", interpolation="bicubic",
+r = ap.apply_motion(_settled(frames[:64]), meta, (127, 127, 127), framing_mode="crop_and_pad", interpolation="bicubic",
                     motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
 ctx.synchronize()
 say("motion apply pass done, device status clean")
