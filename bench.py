@@ -413,7 +413,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = {}
@@ -451,6 +451,9 @@ def main() -> int:
     ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
     ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
     ap_.add_argument("--no-extras", action="store_true", help="skip host_roundtrip / motion_apply (N=1 extras outside the timed loop)")
+    ap_.add_argument("--rehearse-on-one-gpu", action="store_true",
+                     help="N > 1 ranks that all use cuda:0 with a gloo control plane (RCCL refuses two ranks on a device): runs the "
+                          "multi-rank bench code on a one-GPU box; the numbers mean nothing, the line says so")
     ap_.add_argument("--no-checks", action="store_true", help="skip accuracy / batch_invariance / parity_at_size (profiling runs: keeps the timed steps last in a trace)")
     args = ap_.parse_args()
 
@@ -466,8 +469,9 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
 
@@ -477,7 +481,10 @@ def main() -> int:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     import __graft_entry__ as graft
 
@@ -487,7 +494,7 @@ def main() -> int:
     from vstab_amd import host_math as hm
     from vstab_amd import native, nodes
 
-    ctx = native.Context(local_rank)
+    ctx = native.Context(dev_index)
     ctx.set_timing(True)
 
     if args.workload == "c5":
@@ -546,7 +553,7 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -587,6 +594,8 @@ def main() -> int:
                 config["same_clip_on_one_gpu"] = {"frames_per_s": rj["frames_per_s"], "ms_per_step": rj["ms_per_step"],
                                                   "source": "profiles/r03_c4_single_gpu.json (static: `bench.py --gpus 1 --total-frames "
                                                             f"{total}` on one MI355X, not measured in this run)"}
+        if args.rehearse_on_one_gpu:
+            config["rehearsal"] = "all ranks share cuda:0, gloo control plane: a code-path rehearsal, NOT a multi-GPU measurement"
         if use_dist:
             config["rank0_host_ms"] = {k: round(v / args.steps, 3) for k, v in stats.items()}
             config["rank0_host_ms_note"] = ("host wall-clock per phase of rank 0's step; gather_fits + gather_counts = the two "
