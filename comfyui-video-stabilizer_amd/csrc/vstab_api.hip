@@ -316,4 +316,37 @@ int vstab_params_to_matrices(const double* params, int count, int mode, float* m
     return 0;
 }
 
+// _compute_bounding_boxes (stabilizer_utils.py:1010-1034) for a whole clip: the four corners (0,0) (w,0) (0,h) (w,h) through
+// each matrix in fp64 (`m @ corners` with m cast to fp64: products in corner order, summed left to right -- what NumPy's
+// mixed-dtype matmul evaluates, checked bit for bit in tests/test_abi_cpu.py), divided by the third row, min / max per axis
+// with NumPy's NaN-propagating minimum / maximum.
+static inline double np_minimum(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+static inline double np_maximum(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+
+int vstab_bounding_boxes(const float* mats, int count, double width, double height, double* mins, double* maxs)
+{
+    VSTAB_REQUIRE(count >= 0 && (count == 0 || (mats && mins && maxs)), "vstab_bounding_boxes: bad argument");
+    const double cx[4] = {0.0, width, 0.0, width}, cy[4] = {0.0, 0.0, height, height};
+    for (int n = 0; n < count; n++) {
+        const float* M = mats + (size_t)n * 9;
+        double xs[4], ys[4];
+        for (int j = 0; j < 4; j++) {
+            double p[3];
+            for (int i = 0; i < 3; i++) {
+                const double a = (double)M[i * 3 + 0] * cx[j];
+                const double b = (double)M[i * 3 + 1] * cy[j];
+                const double c = (double)M[i * 3 + 2] * 1.0;
+                p[i] = (a + b) + c;
+            }
+            xs[j] = p[0] / p[2];
+            ys[j] = p[1] / p[2];
+        }
+        mins[(size_t)n * 2 + 0] = np_minimum(np_minimum(xs[0], xs[1]), np_minimum(xs[2], xs[3]));
+        mins[(size_t)n * 2 + 1] = np_minimum(np_minimum(ys[0], ys[1]), np_minimum(ys[2], ys[3]));
+        maxs[(size_t)n * 2 + 0] = np_maximum(np_maximum(xs[0], xs[1]), np_maximum(xs[2], xs[3]));
+        maxs[(size_t)n * 2 + 1] = np_maximum(np_maximum(ys[0], ys[1]), np_maximum(ys[2], ys[3]));
+    }
+    return 0;
+}
+
 }  // extern "C"

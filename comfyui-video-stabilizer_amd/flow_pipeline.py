@@ -305,7 +305,7 @@ def _plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, tran
         crop_solution = None
         apply_matrices = native.params_to_matrices(diffs, base_mode)
     output_size = size
-    mins, maxs = hm.bounding_boxes_batched(apply_matrices, width, height)
+    mins, maxs = native.bounding_boxes(apply_matrices, width, height)   # f32 matrices (params_to_matrices / crop solver)
     framing_meta: Dict[str, Any] = {
         "mode": framing_mode,
         "input_size": list(size),

@@ -147,6 +147,9 @@ def apply_value_range(batch, peaks, ctx=None):
     host = getattr(peaks, "_vstab_host", None)
     if host is not None:
         host[1].synchronize()
+        values = host[0].numpy()
+        if not (values > 1.5).any():          # the ComfyUI IMAGE contract (0..1): nothing to do, NumPy on 256 floats
+            return batch, "0_1"
         big = host[0] > 1.5
     else:
         big = peaks.cpu() > 1.5

@@ -148,6 +148,7 @@ _SIGNATURES = {
     "vstab_host_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_transitions_to_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_params_to_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_bounding_boxes": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "vstab_crop_analysis": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_trajectory": (
@@ -231,6 +232,16 @@ def params_to_matrices(params, base_mode: str) -> np.ndarray:
     _check(load_library().vstab_params_to_matrices(p.ctypes.data, p.shape[0], MODES[base_mode], out.ctypes.data),
            "vstab_params_to_matrices")
     return out
+
+
+def bounding_boxes(matrices, width: int, height: int):
+    """_compute_bounding_boxes for a stacked f32 [N,3,3] array (vstab_bounding_boxes) -> (mins [N,2], maxs [N,2]) f64."""
+    m = np.ascontiguousarray(matrices, dtype=np.float32).reshape(-1, 9)
+    mins = np.empty((m.shape[0], 2), np.float64)
+    maxs = np.empty((m.shape[0], 2), np.float64)
+    _check(load_library().vstab_bounding_boxes(m.ctypes.data, m.shape[0], float(width), float(height), mins.ctypes.data,
+                                               maxs.ctypes.data), "vstab_bounding_boxes")
+    return mins, maxs
 
 
 def blur_sample_matrices(matrices64, first: int, count: int, blur: float, samples: int) -> np.ndarray:

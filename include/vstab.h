@@ -293,6 +293,11 @@ int vstab_transitions_to_params(const float* work_mats, int count, int mode, con
                                 float* full_mats, double* params);
 int vstab_params_to_matrices(const double* params, int count, int mode, float* mats);
 
+/* F10 for a whole clip (host pointers): _compute_bounding_boxes (stabilizer_utils.py:1010-1034) -- the four frame corners
+ * through each f32 matrix in fp64, projective division, per-axis min / max (NaN-propagating, as numpy.minimum / maximum).
+ * mats host [count,9] f32; mins, maxs host [count,2] f64. */
+int vstab_bounding_boxes(const float* mats, int count, double width, double height, double* mins, double* maxs);
+
 #ifdef __cplusplus
 }
 #endif

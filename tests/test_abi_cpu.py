@@ -461,3 +461,33 @@ def test_clip_parameter_maps_equal_the_per_item_forms(pkg, mode):
     want = np.stack([hm._params_to_matrix(row, mode) for row in p])
     assert got.dtype == np.float32 and np.array_equal(got, want) and np.array_equal(got, hm.params_to_matrices(p, mode))
     assert native.params_to_matrices(np.zeros((0, native.PARAM_COUNT[mode])), mode).shape == (0, 3, 3)
+
+
+def test_clip_bounding_boxes_equal_numpy(pkg):
+    """vstab_bounding_boxes (host only) against `_compute_bounding_boxes` (stabilizer_utils.py:1010-1034, per item: `m @
+    corners` with an f32 matrix and fp64 corners) and its batched NumPy form: same bits for similarity and perspective
+    matrices, for a projective denominator of zero (inf / NaN corners: NumPy's minimum / maximum propagate NaN) and for
+    the frame sizes of every BASELINE config."""
+    import warnings
+
+    from vstab_amd import host_math as hm
+    from vstab_amd import native
+
+    rng = np.random.default_rng(21)
+    n = 4000
+    mats = np.tile(np.eye(3, dtype=np.float32), (n, 1, 1))
+    mats[:, :2, :2] += rng.normal(0, 0.05, (n, 2, 2)).astype(np.float32)
+    mats[:, :2, 2] = rng.normal(0, 40, (n, 2)).astype(np.float32)
+    mats[n // 2:, 2, :2] = rng.normal(0, 2e-5, (n - n // 2, 2)).astype(np.float32)
+    mats[0, 2] = (0.0, 0.0, 0.0)                      # W == 0 at every corner: 0/0 and x/0
+    mats[1, 2] = (-1.0 / 1920, 0.0, 1.0)              # W == 0 at the right corners only
+    mats[2, 0, 0] = np.nan
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        for (w, h) in ((1920, 1080), (3840, 2160), (854, 480), (73, 45)):
+            mins, maxs = native.bounding_boxes(mats, w, h)
+            want_mins, want_maxs = hm.bounding_boxes_batched(mats, w, h)
+            assert np.array_equal(mins, want_mins, equal_nan=True) and np.array_equal(maxs, want_maxs, equal_nan=True)
+            item_mins, item_maxs = hm._compute_bounding_boxes(list(mats[:300]), w, h)
+            assert np.array_equal(mins[:300], item_mins, equal_nan=True) and np.array_equal(maxs[:300], item_maxs, equal_nan=True)
+    assert native.bounding_boxes(np.zeros((0, 3, 3), np.float32), 10, 10)[0].shape == (0, 2)

@@ -29,15 +29,13 @@ for rep in range(REPS + 5):
     t = lap("1 value range (peaks D2H)", t)
     mats, modes, confs, resids, active = fp.select_transitions(table, "similarity")
     t = lap("2 select_transitions", t)
-    full = hm.rescale_transforms_to_full(np.asarray(mats, np.float32).reshape(-1, 3, 3), (w, h), work)
-    t = lap("3 rescale", t)
-    dp = hm.matrices_to_params(full, "similarity")
-    t = lap("4 matrices_to_params (libm)", t)
+    full, dp = native.transitions_to_params(mats, "similarity", (w, h), work)
+    t = lap("3+4 rescale + matrices_to_params (one library call)", t)
     path, target = ctx.trajectory(dp, 0.5, 16.0, 0.7, False)
     t = lap("5 trajectory (H2D, kernel, D2H, sync)", t)
-    am = hm.params_to_matrices(target - path, "similarity")
-    t = lap("6 params_to_matrices (libm)", t)
-    mins, maxs = hm.bounding_boxes_batched(am, w, h)
+    am = native.params_to_matrices(target - path, "similarity")
+    t = lap("6 params_to_matrices (library call)", t)
+    mins, maxs = native.bounding_boxes(am, w, h)
     ratio = hm._min_content_ratio(mins, maxs, w, h)
     t = lap("7 bounding boxes + ratio", t)
     x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1])); x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
@@ -48,6 +46,6 @@ for rep in range(REPS + 5):
     t = lap("9 warp_batch call (alloc, invert, H2D, launch)", t)
     counts.cpu()
     t = lap("10 wait for the warp", t)
-for k in sorted(acc, key=lambda s: int(s.split()[0])):
+for k in sorted(acc, key=lambda s: int(s.split()[0].split("+")[0])):
     print(f"{k:48s} {acc[k] / REPS * 1e6:8.1f} us")
 print(f"{'total':48s} {sum(acc.values()) / REPS * 1e6:8.1f} us")
