@@ -20,6 +20,7 @@ ap.add_argument("--interp", default="bilinear")
 ap.add_argument("--blur", type=int, default=0, help="samples (0 = plain warp)")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--persp", action="store_true")
+ap.add_argument("--no-count", action="store_true", help="no padded-pixel count (Motion Apply's call shape; bicubic then runs the staged kernel)")
 args = ap.parse_args()
 
 ctx = native.default_context()
@@ -44,7 +45,7 @@ for r in range(args.reps + 2):
         ctx.warp_blur_batch(frames, mats, (w, h), 0.5, args.blur, interp=args.interp, border=border, out=dst, out_mask=mask)
         ms = ctx.last_kernel_ms("warp_blur")
     else:
-        ctx.warp_batch(frames, mats.astype(np.float32), (w, h), interp=args.interp, border=border, want_count=True, out=dst, out_mask=mask)
+        ctx.warp_batch(frames, mats.astype(np.float32), (w, h), interp=args.interp, border=border, want_count=not args.no_count, out=dst, out_mask=mask)
         ms = ctx.last_kernel_ms("warp")
     if r >= 2:
         times.append(ms)
