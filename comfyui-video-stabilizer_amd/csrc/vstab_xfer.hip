@@ -83,8 +83,9 @@ struct Team {
                 });
                 members = t + 1;
             }
-        } catch (const std::system_error&) {
-            // fewer helpers than asked for: members counts the ones that exist
+        } catch (...) {
+            // std::system_error (the box refused a thread) or std::bad_alloc: fewer helpers than asked for -- members counts
+            // the ones that exist; nothing may propagate out of an extern "C" entry point
         }
         if (pthread_barrier_init(&bar, nullptr, (unsigned)members) != 0) {
             members = 1;   // no barrier: the caller's thread does all the copying, parked helpers fall through
