@@ -94,3 +94,36 @@ def test_oracle_warp_reproduces_an_analytic_texture(oracle, interp, bound):
     inside[:, :4] = inside[:, -4:] = False
     err = np.abs(got - want).max(axis=-1)
     assert inside.mean() > 0.85 and err[inside].max() < bound and err[inside].mean() < bound / 4, (err[inside].max(), err[inside].mean())
+
+
+def test_oracle_bilinear_warp_against_scipy_map_coordinates(oracle):
+    """An independent implementation as referee: scipy.ndimage.map_coordinates(order=1) samples the source at the
+    inverse-mapped position of every output pixel (pixel centres at integers, as cv2.warpPerspective has them).  The
+    oracle's unquantised bilinear path (`subpix="exact"`) must agree to float32 rounding of the coordinates (2e-4 on a
+    noise image whose neighbouring pixels differ by up to 1.0), its default 1/32-px path to the quantisation bound
+    (|gradient| <= 1 per px x 1/64 px per axis, two axes, bilinear: 0.04); pixels whose taps touch the border are compared
+    too (constant border, per tap)."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(4)
+    h, w = 90, 120
+    src = rng.random((h, w, 3), dtype=np.float32)
+    m = np.array([[1.03 * np.cos(0.05), -1.03 * np.sin(0.05), 4.3], [1.03 * np.sin(0.05), 1.03 * np.cos(0.05), -3.7], [1.5e-4, -1e-4, 1.0]])
+    inv = np.linalg.inv(m.astype(np.float32).astype(np.float64))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = inv[2, 0] * xx + inv[2, 1] * yy + inv[2, 2]
+    sx = (inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]) / den
+    sy = (inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]) / den
+    border = (0.25, 0.5, 0.75)
+    want = np.stack([ndimage.map_coordinates(src[..., c].astype(np.float64), [sy, sx], order=1, mode="constant", cval=border[c])
+                     for c in range(3)], axis=-1)
+    # scipy treats everything beyond the last pixel centre as `cval` without blending; OpenCV blends the border colour in
+    # per tap.  Compare where all four taps are inside, and separately check that far-outside pixels are pure border.
+    inside = (sx >= 0) & (sx <= w - 1) & (sy >= 0) & (sy <= h - 1)
+    exact, _ = oracle.warp_frame(src, m.astype(np.float32), (w, h), interp="bilinear", border=border, subpix="exact")
+    q5, _ = oracle.warp_frame(src, m.astype(np.float32), (w, h), interp="bilinear", border=border, subpix="q5")
+    assert inside.mean() > 0.8
+    assert np.abs(exact - want)[inside].max() < 2e-4
+    assert np.abs(q5 - want)[inside].max() < 0.04 and np.abs(q5 - want)[inside].mean() < 0.008
+    far = (sx < -2) | (sx > w + 1) | (sy < -2) | (sy > h + 1)
+    assert far.any() and np.array_equal(q5[far], np.broadcast_to(np.float32(border), q5.shape)[far])
