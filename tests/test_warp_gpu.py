@@ -293,3 +293,18 @@ def test_blur_single_frame_quirk_on_the_staged_path(ctx, oracle, interp):
     dst, mask = ctx.warp_blur_batch(frames, mats, (200, 160), 0.5, 9, interp=interp, border=BORDER)
     assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
     assert abs(float(ref_mask[0, 80, 100]) - (1.0 - 1.0 / 9.0)) < 1e-6
+
+
+@pytest.mark.parametrize("interp", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("kind", ["flip", "quarter_turn", "magnify", "minify", "horizon", "far"])
+def test_blur_staged_path_under_extreme_maps(ctx, oracle, kind, interp):
+    """The tile classification of warp_blur_kernel under maps that stress its assumptions: mirrored and rotated axes
+    (the per-pixel evaluation is monotone DEcreasing: the corners still bound it), a 37-137x zoom (a source window of a
+    few texels), a 20-50x reduction (a window far too large to stage: general loop), a projective horizon inside the frame
+    (non-affine samples: general loop) and a map that leaves the source entirely.  Bit-exact against the oracle."""
+    n, sh, sw = 3, 270, 480
+    frames = synth_frames(n, sh, sw, seed=17)
+    mats = make_matrices(n, sw, sh, kind, seed=3)
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (sw, sh), 0.6, 9, interp=interp, border=BORDER)
+    dst, mask = ctx.warp_blur_batch(frames, mats, (sw, sh), 0.6, 9, interp=interp, border=BORDER)
+    assert np.array_equal(dst.cpu().numpy(), ref, equal_nan=True) and np.array_equal(mask.cpu().numpy(), ref_mask)
