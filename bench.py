@@ -27,6 +27,12 @@ Also on the JSON line (rank 0):
                  average launch time from HIP events on the launch stream
   cpu_baseline   the CPU oracle (a C restatement of the reference's OpenCV path; "port") timed on this host's cores
                  over a bounded sample of the same clip (N = 1 only)
+  accuracy       (N = 1) the 255 transitions the timed configuration reports against the clip's ANALYTIC motion
+                 M_{i+1} M_i^-1 (px at working resolution, max / mean / p99), for the HIP run and for the CPU port
+  parity_at_size (N = 1, inside the cpu_baseline leg: the oracle is the checker) the HIP run against the oracle's run of the
+                 same 256 frames: matrices, confidences, every output pixel, every mask pixel, padding statistics
+  batch_invariance (N = 1) pairs {0,127,254} re-run as 2-frame clips and frames {0,127,255} warped alone == the clip run
+  c5             (N > 1, or --force-dist) BASELINE configs[4] on the same ranks, outside the timed loop
   host_roundtrip the node as ComfyUI calls it: CPU tensor in -> CPU tensors out (PCIe-inclusive; never `value`)
   motion_apply   Motion Apply rates for C3 (1080p, bicubic, blur 0.5, S=17) and C5's per-GPU share (4K, bilinear,
                  blur 0.5, S=33), device-resident (N = 1 only; measured outside the timed loop)
