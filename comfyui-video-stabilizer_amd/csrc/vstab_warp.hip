@@ -638,9 +638,9 @@ int launch_blur(WarpArgs a, bool with_mask, hipStream_t st)
     a.tiles_y = (a.dh + TILE_H - 1) / TILE_H;
     const unsigned long long blocks = (unsigned long long)a.tiles_x * a.tiles_y * a.n;
     VSTAB_REQUIRE(blocks > 0 && blocks < 0x7fffffffULL, "warp: grid of %llu blocks is out of range", blocks);
-    // fast-path preconditions that do not depend on the block: a thread's two pixels share OpenCV's column block, a
-    // frame's byte offsets fit 32 bits, u24 multiplies are exact (check_common: sh, sw <= 32767)
-    a.blur_fast = ((a.bw0 >= a.dw) || (a.bw0 % TILE_W == 0)) && ((unsigned long long)a.sh * a.sw * 12ULL < (1ULL << 32)) ? 1 : 0;
+    // staged-path precondition that does not depend on the block: a thread's two pixels share OpenCV's column block (the
+    // u24 multiply of the window index is exact: check_common has sh, sw <= 32767 and the window is at most 4864 texels)
+    a.blur_fast = ((a.bw0 >= a.dw) || (a.bw0 % TILE_W == 0)) ? 1 : 0;
     // the prologue (corner classification, staging, two barriers) is amortised over the samples: measured break-even
     // S = 4 for bilinear (S = 3: 2.00 vs 1.86 ms per 64 x 1080p; S = 5: 2.38 vs 2.50), below 3 for bicubic
     if (INTERP == VSTAB_INTERP_BILINEAR && a.nxf_per_frame < 4) a.blur_fast = 0;
