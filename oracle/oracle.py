@@ -29,7 +29,9 @@ MODE_NAMES = {v: k for k, v in MODES.items()}
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (a few seconds)."""
-    if force or not _LIB_PATH.exists():
+    stale = not _LIB_PATH.exists() or any(
+        f.stat().st_mtime > _LIB_PATH.stat().st_mtime for pat in ("vo_*.c", "*.h", "Makefile") for f in _HERE.glob(pat))
+    if force or stale:
         subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -241,6 +243,19 @@ def dis_flow(i0, i1, params=None):
     if rc != 0:
         raise ValueError(f"vo_dis_calc: unsupported configuration (rc={rc})")
     return flow
+
+
+def dis_gradients(img, patch_size=8, patch_stride=4):
+    """Sobel gradients (s16) and structure-tensor planes [5,hs,ws] of one DIS level image (test-only view)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    ix = np.empty((h, w), np.int16)
+    iy = np.empty((h, w), np.int16)
+    hs, ws = 1 + (h - patch_size) // patch_stride, 1 + (w - patch_size) // patch_stride
+    tensor = np.empty((5, hs, ws), np.float32)
+    lib().vo_dis_gradients(_ptr(img, C.c_uint8), h, w, patch_size, patch_stride, _ptr(ix, C.c_int16), _ptr(iy, C.c_int16),
+                           _ptr(tensor, C.c_float))
+    return ix, iy, tensor
 
 
 class dis_sum_order:

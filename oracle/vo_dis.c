@@ -166,6 +166,24 @@ static void structure_tensor(Level* L, int psz, int pstr)
     }
 }
 
+/* Test-only view of prepareBuffers' per-level products for ONE image (tests/test_referee_cpu.py compares them with an
+ * independent torch.nn.functional.conv2d evaluation): Sobel gradients and, if `tensor` is given, the five structure-tensor
+ * planes [5][hs][ws] in the order xx, yy, xy, x, y. */
+void vo_dis_gradients(const uint8_t* I, int h, int w, int psz, int pstr, short* Ix, short* Iy, float* tensor)
+{
+    sobel_s16(I, h, w, Ix, Iy);
+    if (!tensor) return;
+    Level L;
+    memset(&L, 0, sizeof(L));
+    L.w = w; L.h = h;
+    L.ws = 1 + (w - psz) / pstr;
+    L.hs = 1 + (h - psz) / pstr;
+    L.Ix = Ix; L.Iy = Iy;
+    const size_t ns = (size_t)L.ws * L.hs;
+    L.xx = tensor; L.yy = tensor + ns; L.xy = tensor + 2 * ns; L.sx = tensor + 3 * ns; L.sy = tensor + 4 * ns;
+    structure_tensor(&L, psz, pstr);
+}
+
 /* pyramid of one frame: levels [finest, coarsest] */
 static void build_levels(const uint8_t* gray, int h, int w, const vo_dis_params* p, int coarsest,
                          Level* L /* indexed by scale */, int want_grad, int want_ext)

@@ -66,6 +66,8 @@ int vo_dis_coarsest_scale(int h, int w, int patch_size);
  * 0 = the XOR butterfly of round 1 (deviation measurement only).  Process-global; set before calling vo_dis_calc*. */
 void vo_dis_set_sum_order(int order);
 int vo_dis_get_sum_order(void);
+/* test-only: Sobel gradients (s16) and the five structure-tensor planes [5][hs][ws] (xx, yy, xy, x, y) of one level image */
+void vo_dis_gradients(const uint8_t* I, int h, int w, int psz, int pstr, short* Ix, short* Iy, float* tensor);
 
 /* ---- sampling + model fit (vo_fit.c) ---- */
 typedef struct vo_fit_result {

@@ -1,0 +1,401 @@
+"""Independent referees for the oracle's OpenCV primitives (CPU suite; runs wherever torch / numpy / scipy import).
+
+No `cv2` exists in the build container or on the GPU box, so the oracle's restatement of cv2.warpPerspective, cv2.resize,
+cv2.cvtColor, Sobel / Scharr / pyrDown and the RANSAC refits is "parity unpinned" against OpenCV itself.  What
+CAN be shown here is that the restatement is the operation it claims to be, by comparing it with implementations that
+share no code and no author with it:
+
+  * warpPerspective, INTER_LINEAR / INTER_CUBIC (A = -0.75) / INTER_NEAREST, BORDER_CONSTANT per tap  ->
+      torch.nn.functional.grid_sample (float64, align_corners=True, padding_mode="zeros") at the inverse-mapped pixel centres;
+      (a) at coordinates quantised to 1/32 px the way cv::remap does it: agreement to f32 rounding -- taps, weights, border
+      blending and fraction convention all pinned; (b) at the unquantised coordinates: agreement within the image's own
+      1/32-px quantisation bound (what the reference's OpenCV < 4.11 does and the >= 4.11 bilinear kernels do not);
+  * resize INTER_AREA  ->  F.avg_pool2d + the stated integer rounding (2x, 3x, 4x), and an integral-image (cumulative sum)
+      evaluation of the box integral for the non-integer ratios of the DIS pyramid (135 -> 67 etc.);
+  * resize INTER_LINEAR (flow upsampling)  ->  F.interpolate(mode="bilinear", align_corners=False);
+  * Sobel 3x3 / Scharr / 5-tap pyrDown / structure-tensor box sums / cornerMinEigenVal  ->  F.conv2d on reflect-101 padded
+      integers (exact) or float64;
+  * cvtColor(RGB2GRAY) + truncating u8 cast  ->  float64 numpy;
+  * estimateAffinePartial2D / findHomography refits  ->  numpy.linalg.lstsq, SVD-DLT, scipy.optimize.least_squares;
+  * translation mode  ->  numpy.median.
+
+Reference call sites these primitives serve: nodes/video_stabilizer_flow.py:82-86,140,163-184,561-582,
+nodes/stabilizer_utils.py:236-242,271-276, nodes/motion_apply.py:94-115,173-190, nodes/video_stabilizer_classic.py:76-96.
+The HIP kernels equal the oracle bit for bit (tests/test_*_gpu.py), so what is shown for the checker holds for the product."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import similarity
+
+
+# ----------------------------------------------------------------------------------------------- warp
+def _smooth_image(h, w, seed):
+    """Band-limited colour texture in [0,1]: neighbouring pixels differ by a few 1e-2, so the 1/32-px bound is meaningful."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3))
+    for c in range(3):
+        for _ in range(6):
+            fx, fy = rng.uniform(-0.35, 0.35, 2)
+            img[..., c] += rng.uniform(0.3, 1.0) * np.cos(fx * xx + fy * yy + rng.uniform(0, 6.28))
+        img[..., c] = 0.5 + 0.45 * img[..., c] / np.abs(img[..., c]).max()
+    return img.astype(np.float32)
+
+
+def _maps(w, h):
+    persp = similarity(3.3, -2.1, 0.03, 1.02, w / 2, h / 2)
+    persp[2, 0], persp[2, 1] = 2.5e-4, -1.5e-4
+    return {
+        "rotation": similarity(0.0, 0.0, np.deg2rad(7.0), 1.0, w / 2, h / 2),
+        "zoom_in": similarity(1.37, -0.61, 0.0, 1.31, w / 2, h / 2),
+        "zoom_out": similarity(-2.2, 3.9, -0.01, 0.72, w / 2, h / 2),
+        "perspective": persp,
+        "mostly_outside": similarity(0.55 * w, -0.4 * h, 0.2, 1.0),
+    }
+
+
+def _source_coordinates(m32, w, h):
+    """Float64 source position of every output pixel centre (cv2.warpPerspective without WARP_INVERSE_MAP: M is f32,
+    converted to f64 and inverted in f64; pixel centres at integer coordinates)."""
+    inv = np.linalg.inv(m32.astype(np.float64))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = inv[2, 0] * xx + inv[2, 1] * yy + inv[2, 2]
+    return (inv[0, 0] * xx + inv[0, 1] * yy + inv[0, 2]) / den, (inv[1, 0] * xx + inv[1, 1] * yy + inv[1, 2]) / den
+
+
+def _grid_sample(src, sx, sy, mode):
+    """torch's sampler at source pixel coordinates (sx, sy), float64, zero padding per tap."""
+    h, w = src.shape[:2]
+    t = torch.from_numpy(np.ascontiguousarray(src, np.float64))
+    t = (t[..., None] if t.ndim == 2 else t).permute(2, 0, 1)[None]
+    grid = torch.from_numpy(np.stack([2.0 * sx / (w - 1) - 1.0, 2.0 * sy / (h - 1) - 1.0], -1))[None]
+    out = F.grid_sample(t, grid, mode=mode, padding_mode="zeros", align_corners=True)
+    return out[0].permute(1, 2, 0).numpy()
+
+
+def _referee_warp(src, sx, sy, mode, border):
+    """BORDER_CONSTANT blends the border colour in per tap.  The interpolation weights sum to one (bilinear exactly;
+    bicubic by construction, c3 = 1 - c0 - c1 - c2), so that is sample(src) + border * (1 - sample(ones))."""
+    inside = _grid_sample(np.ones(src.shape[:2]), sx, sy, mode)
+    return _grid_sample(src, sx, sy, mode) + np.asarray(border, np.float64) * (1.0 - inside)
+
+
+def _quantise(v):
+    return np.rint(v * 32.0) / 32.0          # cvRound (half to even) of the coordinate in 1/32-px units
+
+
+@pytest.mark.parametrize("interp,mode,tol", [("bilinear", "bilinear", 2e-6), ("bicubic", "bicubic", 8e-6)])
+@pytest.mark.parametrize("name", ["rotation", "zoom_in", "zoom_out", "perspective", "mostly_outside"])
+@pytest.mark.parametrize("border", [(0.0, 0.0, 0.0), (0.25, 0.5, 0.75)])
+def test_warp_equals_grid_sample_at_quantised_coordinates(oracle, interp, mode, tol, name, border):
+    """Every output pixel, border band included: taps, weight tables (bicubic A = -0.75), per-tap border blending and the
+    floor / fraction split of the 1/32-px coordinate are those of an independent sampler -- to float32 rounding."""
+    h, w = 96, 128
+    src = np.random.default_rng(11).random((h, w, 3), dtype=np.float32)          # white noise: nothing averages out
+    m32 = _maps(w, h)[name].astype(np.float32)
+    sx, sy = _source_coordinates(m32, w, h)
+    want = _referee_warp(src, _quantise(sx), _quantise(sy), mode, border)
+    got, _ = oracle.warp_frame(src, m32, (w, h), interp=interp, border=border)
+    err = np.abs(got - want)
+    # a coordinate within 1e-9 of a rounding tie may legitimately round the other way (the oracle multiplies by 32/W,
+    # this test divides first); none occurs on these maps, but say so if one ever does instead of widening the bound
+    assert err.max() <= tol, (name, interp, float(err.max()), int((err > tol).sum()))
+
+
+@pytest.mark.parametrize("interp,mode,lipschitz", [("bilinear", "bilinear", 1.0), ("bicubic", "bicubic", 2.0)])
+@pytest.mark.parametrize("name", ["rotation", "zoom_in", "zoom_out", "perspective"])
+def test_warp_within_quantisation_bound_of_unquantised_grid_sample(oracle, interp, mode, lipschitz, name):
+    """Against the sampler at the TRUE inverse-mapped positions: the only difference left is OpenCV's 1/32-px coordinate
+    rounding (<= 1/64 px per axis), bounded by the image's own neighbour differences; zero border, whole image."""
+    h, w = 108, 192
+    src = _smooth_image(h, w, 5)
+    m32 = _maps(w, h)[name].astype(np.float32)
+    sx, sy = _source_coordinates(m32, w, h)
+    want = _referee_warp(src, sx, sy, mode, (0.0, 0.0, 0.0))
+    got, _ = oracle.warp_frame(src, m32, (w, h), interp=interp, border=(0.0, 0.0, 0.0))
+    gx = np.abs(np.diff(src.astype(np.float64), axis=1)).max()
+    gy = np.abs(np.diff(src.astype(np.float64), axis=0)).max()
+    interior = (sx >= 2) & (sx <= w - 3) & (sy >= 2) & (sy <= h - 3)
+    err = np.abs(got - want).max(axis=-1)
+    bound = lipschitz * (gx + gy) / 64.0
+    assert interior.mean() > 0.4 and err[interior].max() <= bound, (name, interp, float(err[interior].max()), bound)
+    # border band: a tap row/column switches between image and zero border -> the step is the pixel value itself (<= 1)
+    assert err.max() <= lipschitz * 1.0 / 32.0 + bound, float(err.max())
+    assert err[interior].mean() < bound / 3
+
+
+@pytest.mark.parametrize("name", ["rotation", "zoom_out", "perspective"])
+def test_exact_subpixel_bilinear_equals_unquantised_grid_sample(oracle, name):
+    """`subpix="exact"` (the OpenCV >= 4.11 INTER_LINEAR form): no coordinate quantisation, so the agreement is down to the
+    float32 rounding of the coordinates (1e-5 px on a noise image with unit steps)."""
+    h, w = 96, 128
+    src = np.random.default_rng(12).random((h, w, 3), dtype=np.float32)
+    m32 = _maps(w, h)[name].astype(np.float32)
+    sx, sy = _source_coordinates(m32, w, h)
+    border = (0.1, 0.2, 0.3)
+    want = _referee_warp(src, sx, sy, "bilinear", border)
+    got, _ = oracle.warp_frame(src, m32, (w, h), interp="bilinear", border=border, subpix="exact")
+    assert np.abs(got - want).max() < 2e-4
+
+
+@pytest.mark.parametrize("name", ["rotation", "zoom_in", "zoom_out", "perspective", "mostly_outside"])
+def test_nearest_coverage_equals_grid_sample_nearest(oracle, name):
+    """The coverage warp of flow.py:575-582 (ones, INTER_NEAREST, zero border): round-half-even of the source position,
+    in-bounds test -- torch's nearest sampler does the same with nearbyint."""
+    h, w = 96, 128
+    m32 = _maps(w, h)[name].astype(np.float32)
+    sx, sy = _source_coordinates(m32, w, h)
+    want = _grid_sample(np.ones((h, w)), sx, sy, "nearest")[..., 0]
+    _, cov = oracle.warp_frame(np.ones((h, w, 3), np.float32), m32, (w, h), interp="bilinear")
+    tie = (np.abs(sx - np.floor(sx) - 0.5) < 1e-7) | (np.abs(sy - np.floor(sy) - 0.5) < 1e-7)
+    assert np.array_equal(cov[~tie] > 0.5, want[~tie] > 0.5) and 0.0 < (cov > 0.5).mean() <= 1.0
+
+
+def test_invert3x3_equals_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        m = similarity(*rng.uniform(-20, 20, 2), rng.uniform(-1, 1), rng.uniform(0.5, 2.0))
+        m[2, :2] = rng.uniform(-1e-3, 1e-3, 2)
+        assert np.allclose(oracle.invert3x3(m), np.linalg.inv(m), rtol=1e-12, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------- resize / gray
+def _u8_image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 110 + 90 * np.sin(xx * 0.05) * np.cos(yy * 0.08)
+    return np.clip(base + rng.integers(-40, 40, (h, w)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_inter_area_integer_ratio_equals_avg_pool(oracle, k):
+    """INTER_AREA at an integer ratio is the box mean: 2x2 -> (a+b+c+d+2)>>2 (round half up), otherwise the mean rounded
+    half to even (saturate_cast).  F.avg_pool2d in float64 is exact on 8-bit sums."""
+    h, w = 54 * k, 96 * k
+    img = _u8_image(h, w, k)
+    mean = F.avg_pool2d(torch.from_numpy(img.astype(np.float64))[None, None], k)[0, 0].numpy()
+    want = np.floor(mean + 0.5) if k == 2 else np.rint(mean)
+    got = oracle.resize_area_u8(img, (w // k, h // k))
+    assert np.array_equal(got, want.astype(np.uint8))
+
+
+def _area_resize_by_integral(img, dh, dw):
+    """Box integral of the piecewise-constant image over each destination cell, via cumulative sums (float64)."""
+    def along(a, dn):
+        n = a.shape[0]
+        scale = n / dn
+        cum = np.concatenate([np.zeros((1,) + a.shape[1:]), np.cumsum(a, axis=0)], 0)      # integral up to integer x
+
+        def integral(x):
+            i = np.minimum(np.floor(x).astype(int), n - 1)
+            return cum[i] + (x - i)[(...,) + (None,) * (a.ndim - 1)] * a[i]
+        edges = np.arange(dn + 1) * scale
+        edges[-1] = n
+        return (integral(edges[1:]) - integral(edges[:-1])) / scale
+    return along(along(img.astype(np.float64), dh).T, dw).T
+
+
+@pytest.mark.parametrize("size,out", [((135, 240), (67, 120)), ((67, 120), (33, 60)), ((33, 60), (16, 30)), ((45, 73), (22, 36))])
+def test_inter_area_general_ratio_equals_box_integral(oracle, size, out):
+    """The DIS pyramid's non-integer steps (135 -> 67 rows ...): OpenCV's DecimateAlpha tap tables in float32 against the
+    exact box integral; differences only where the float32 sum lands within rounding of a .5 tie."""
+    img = _u8_image(size[0], size[1], 3)
+    want = _area_resize_by_integral(img, out[0], out[1])
+    got = oracle.resize_area_u8(img, (out[1], out[0])).astype(np.float64)
+    assert np.abs(got - want).max() <= 0.5 + 1e-3
+    assert (got != np.rint(want)).mean() < 2e-3
+
+
+@pytest.mark.parametrize("size,out", [((16, 30), (33, 60)), ((67, 120), (135, 240)), ((135, 240), (540, 960))])
+def test_resize_linear_equals_torch_interpolate(oracle, size, out):
+    """cv2.resize(INTER_LINEAR) on float32 (DIS's flow upsampling, incl. the final x4 of flow.py:140's output) uses
+    half-pixel centres with clamped taps: F.interpolate(mode="bilinear", align_corners=False)."""
+    rng = np.random.default_rng(2)
+    src = (rng.standard_normal((size[0], size[1], 2)) * 3.0).astype(np.float32)
+    want = F.interpolate(torch.from_numpy(src.astype(np.float64)).permute(2, 0, 1)[None], size=out, mode="bilinear",
+                         align_corners=False)[0].permute(1, 2, 0).numpy()
+    got = oracle.resize_linear_f32(src, (out[1], out[0]))
+    # OpenCV forms the tap position in float32: half an ulp of a coordinate near 128 (4e-6 px) times the largest step
+    # between neighbours (~ 15 on this noise field) -> a few 1e-5
+    step = max(np.abs(np.diff(src, axis=0)).max(), np.abs(np.diff(src, axis=1)).max())
+    assert np.abs(got - want).max() < 8e-6 * step
+
+
+def test_rgb2gray_equals_float64_formula_and_truncates(oracle):
+    rng = np.random.default_rng(9)
+    rgb = rng.random((60, 83, 3), dtype=np.float32)
+    y64 = rgb.astype(np.float64) @ np.array([0.299, 0.587, 0.114])
+    assert np.abs(oracle.rgb2gray_f32(rgb) - y64).max() < 2e-7
+    want = np.floor(np.clip(y64 * 255.0, 0, 255))                     # utils.py:242: clip(gray*255).astype(uint8) truncates
+    got = oracle.rgb2gray_u8(rgb).astype(np.float64)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 1e-3
+    # truncation, not rounding: a mid-gray of 127.9/255 must come out as 127
+    px = np.full((1, 8, 3), 127.9 / 255.0, np.float32)
+    assert np.all(oracle.rgb2gray_u8(px) == 127)
+
+
+# ----------------------------------------------------------------------------------------------- integer stencils
+def _conv_reflect101(img, kernel, stride=1):
+    k = torch.tensor(kernel, dtype=torch.float64)[None, None]
+    ph, pw = k.shape[2] // 2, k.shape[3] // 2
+    t = F.pad(torch.from_numpy(img.astype(np.float64))[None, None], (pw, pw, ph, ph), mode="reflect")    # reflect = 101
+    return F.conv2d(t, k, stride=stride)[0, 0].numpy()
+
+
+def test_dis_sobel_and_structure_tensor_equal_conv2d(oracle):
+    """spatialGradient (3x3 Sobel, s16, BORDER_REFLECT_101) and the 8x8 / stride-4 structure-tensor sums of DIS."""
+    img = _u8_image(67, 120, 4)
+    ix, iy, tensor = oracle.dis_gradients(img, 8, 4)
+    kx = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]                            # cross-correlation form, as conv2d applies it
+    ky = [[-1, -2, -1], [0, 0, 0], [1, 2, 1]]
+    wx, wy = _conv_reflect101(img, kx), _conv_reflect101(img, ky)
+    assert np.array_equal(ix, wx.astype(np.int16)) and np.array_equal(iy, wy.astype(np.int16))
+    ones = torch.ones(1, 1, 8, 8, dtype=torch.float64)
+    for plane, prod in zip(tensor, [wx * wx, wy * wy, wx * wy, wx, wy]):
+        want = F.conv2d(torch.from_numpy(prod)[None, None], ones, stride=4)[0, 0].numpy()
+        assert plane.shape == want.shape
+        # OpenCV keeps these as float32 running sums; the exact integers can exceed 2^24
+        assert np.abs(plane - want).max() <= 4e-7 * np.abs(want).max() + 1e-3
+
+
+def test_scharr_and_pyrdown_equal_conv2d(oracle):
+    """calcOpticalFlowPyrLK's pyramid: Scharr derivatives (3,10,3) x (-1,0,1) and the 5-tap (1,4,6,4,1) pyrDown with
+    (sum + 128) >> 8, both BORDER_REFLECT_101, exact integers."""
+    img = _u8_image(61, 94, 6)
+    d = oracle.scharr_deriv(img)
+    sx = [[-3, 0, 3], [-10, 0, 10], [-3, 0, 3]]
+    sy = [[-3, -10, -3], [0, 0, 0], [3, 10, 3]]
+    assert np.array_equal(d[..., 0], _conv_reflect101(img, sx).astype(np.int16))
+    assert np.array_equal(d[..., 1], _conv_reflect101(img, sy).astype(np.int16))
+    g = np.outer([1, 4, 6, 4, 1], [1, 4, 6, 4, 1]).tolist()
+    want = (_conv_reflect101(img, g, stride=2).astype(np.int64) + 128) >> 8
+    got = oracle.pyr_down(img)
+    assert got.shape == ((61 + 1) // 2, (94 + 1) // 2) and np.array_equal(got, want.astype(np.uint8))
+
+
+def test_min_eigen_val_equals_float64_definition(oracle):
+    """cv2.cornerMinEigenVal behind goodFeaturesToTrack(blockSize=21) (classic.py:76-83): Sobel scaled by
+    1/(255 * 4 * block), unnormalised block sums with a reflect-101 border, smaller eigenvalue of [[a, b], [b, c]]."""
+    block = 21
+    img = _u8_image(80, 110, 8)
+    s = 1.0 / (255.0 * 4.0 * block)
+    dx = _conv_reflect101(img, [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]) * s
+    dy = _conv_reflect101(img, [[-1, -2, -1], [0, 0, 0], [1, 2, 1]]) * s
+    box = np.ones((block, block)).tolist()
+    a, b, c = (_conv_reflect101(p, box) for p in (dx * dx, dx * dy, dy * dy))
+    want = 0.5 * (a + c) - np.sqrt((0.5 * (a - c)) ** 2 + b * b)
+    got = oracle.min_eigen_val(img, block)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+# ----------------------------------------------------------------------------------------------- model fits
+def _grid_points(w=960, h=540, step=8):
+    ys, xs = np.mgrid[0:h:step, 0:w:step]
+    return np.stack([xs.ravel(), ys.ravel()], -1).astype(np.float64)
+
+
+def _lstsq_similarity(p, q):
+    """min sum |[[a, -b], [b, a]] p + t - q|^2 is linear in (a, b, tx, ty)."""
+    A = np.zeros((2 * len(p), 4))
+    A[0::2] = np.stack([p[:, 0], -p[:, 1], np.ones(len(p)), np.zeros(len(p))], -1)
+    A[1::2] = np.stack([p[:, 1], p[:, 0], np.zeros(len(p)), np.ones(len(p))], -1)
+    a, b, tx, ty = np.linalg.lstsq(A, q.reshape(-1), rcond=None)[0]
+    return np.array([[a, -b, tx], [b, a, ty]])
+
+
+def test_similarity_fit_equals_lstsq(oracle):
+    """estimateAffinePartial2D(RANSAC 2.0, refineIters 10) as restated: exact on noise-free data under 30 % gross
+    outliers, and on noisy data the least-squares solution over the inlier set it reports (the refit problem is linear)."""
+    rng = np.random.default_rng(5)
+    p = _grid_points()
+    true = similarity(3.2, -1.7, 0.004, 1.003, 480, 270)
+    q = p @ true[:2, :2].T + true[:2, 2]
+    q_out = q.copy()
+    bad = rng.random(len(p)) < 0.3
+    q_out[bad] += rng.uniform(5, 40, (int(bad.sum()), 2)) * rng.choice([-1.0, 1.0], (int(bad.sum()), 2))   # none within 2 px
+    m, inl = oracle.estimate_affine_partial2d(p, q_out)
+    assert m is not None and np.array_equal(inl.astype(bool), ~bad)
+    assert np.abs(m[:, :2] - true[:2, :2]).max() < 2e-7 and np.abs(m[:, 2] - true[:2, 2]).max() < 1e-4      # f32 inputs
+    noisy = q + rng.normal(0, 0.3, q.shape)
+    m, inl = oracle.estimate_affine_partial2d(p, noisy)
+    keep = inl.astype(bool)
+    assert keep.mean() > 0.95            # the mask is the best minimal-sample model's, not the refit's (as in OpenCV)
+    p32, q32 = p.astype(np.float32).astype(np.float64), noisy.astype(np.float32).astype(np.float64)
+    want = _lstsq_similarity(p32[keep], q32[keep])
+    assert np.abs(m[:, :2] - want[:, :2]).max() < 1e-9 and np.abs(m[:, 2] - want[:, 2]).max() < 1e-6
+
+
+def _dlt(p, q):
+    """Homography by SVD of the 2n x 9 direct linear transform on Hartley-normalised points."""
+    def norm(x):
+        c = x.mean(0)
+        s = np.sqrt(2.0) / np.sqrt(((x - c) ** 2).sum(1)).mean()
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1]])
+        return (x - c) * s, T
+    pn, Tp = norm(p)
+    qn, Tq = norm(q)
+    A = np.zeros((2 * len(p), 9))
+    A[0::2, 0:2], A[0::2, 2], A[0::2, 6:8], A[0::2, 8] = pn, 1, -qn[:, :1] * pn, -qn[:, 0]
+    A[1::2, 3:5], A[1::2, 5], A[1::2, 6:8], A[1::2, 8] = pn, 1, -qn[:, 1:] * pn, -qn[:, 1]
+    H = np.linalg.svd(A)[2][-1].reshape(3, 3)
+    H = np.linalg.inv(Tq) @ H @ Tp
+    return H / H[2, 2]
+
+
+def _project(H, p):
+    z = p @ H[2, :2] + H[2, 2]
+    return (p @ H[:2, :2].T + H[:2, 2]) / z[:, None]
+
+
+def test_homography_fit_equals_dlt_and_least_squares(oracle):
+    """findHomography(RANSAC 2.5) as restated: noise-free correspondences under 30 % outliers give the SVD-DLT homography;
+    noisy ones give the minimiser of the reprojection error over its inliers (scipy's Levenberg-Marquardt from the DLT
+    start) -- compared as point transfers over the frame, which is what the stabiliser consumes."""
+    from scipy.optimize import least_squares
+
+    rng = np.random.default_rng(6)
+    p = _grid_points()
+    true = similarity(2.1, 1.3, -0.003, 0.998, 480, 270)
+    true[2, 0], true[2, 1] = 3e-6, -2e-6
+    q = _project(true, p)
+    q_out = q.copy()
+    bad = rng.random(len(p)) < 0.3
+    q_out[bad] += rng.uniform(5, 40, (int(bad.sum()), 2)) * rng.choice([-1.0, 1.0], (int(bad.sum()), 2))   # none within 2.5 px
+    H, inl = oracle.find_homography(p, q_out)
+    keep = inl.astype(bool)
+    assert H is not None and np.array_equal(keep, ~bad)
+    p32, q32 = p.astype(np.float32).astype(np.float64), q_out.astype(np.float32).astype(np.float64)
+    want = _dlt(p32[keep], q32[keep])
+    corners = np.array([[0, 0], [959, 0], [0, 539], [959, 539], [480, 270.0]])
+    assert np.abs(_project(H, corners) - _project(want, corners)).max() < 2e-4          # f32 inputs: 3e-5 px of input noise
+    assert np.abs(_project(H, corners) - _project(true, corners)).max() < 2e-4
+
+    noisy = q + rng.normal(0, 0.3, q.shape)
+    H, inl = oracle.find_homography(p, noisy)
+    keep = inl.astype(bool)
+    assert keep.mean() > 0.95            # the mask is the best minimal-sample model's, not the refit's (as in OpenCV)
+    p32, q32 = p.astype(np.float32).astype(np.float64)[keep], noisy.astype(np.float32).astype(np.float64)[keep]
+    start = _dlt(p32, q32)
+    sol = least_squares(lambda h: (_project(np.append(h, 1.0).reshape(3, 3), p32) - q32).ravel(), start.ravel()[:8],
+                        method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    best = np.append(sol.x, 1.0).reshape(3, 3)
+    assert np.abs(_project(H, corners) - _project(best, corners)).max() < 1e-4
+    cost = lambda M: ((_project(M, p32) - q32) ** 2).sum()
+    assert cost(H) <= cost(best) * (1 + 1e-9) + 1e-9 and cost(H) <= cost(start)
+
+
+def test_translation_mode_equals_numpy_median(oracle):
+    """flow.py:191-208: per-axis np.median of the stride-8 samples, confidence = valid / total."""
+    rng = np.random.default_rng(7)
+    flow = (rng.standard_normal((135, 240, 2)) * 0.7 + np.array([1.25, -0.5])).astype(np.float32)
+    out, nv, nt = oracle.fit_all_modes(flow, 8, "translation")
+    m = out["translation"]["matrix"]
+    ys, xs = np.mgrid[0:135:8, 0:240:8]
+    prev = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float32)
+    s = (prev + flow[0::8, 0::8].reshape(-1, 2)) - prev                # flow.py:147,192: shifts = curr - prev, in float32
+    assert nv == nt == len(s) and len(s) % 2 == 0                      # even count: the mean of the two middle values
+    assert m[0, 2] == np.float32(np.median(s[:, 0])) and m[1, 2] == np.float32(np.median(s[:, 1]))
+    assert np.array_equal(m[:2, :2], np.eye(2, dtype=np.float32)) and out["translation"]["confidence"] == 1.0
