@@ -25,8 +25,11 @@ anything touches the GPU and relays its output (never an exec).
 Also on the JSON line (rank 0):
   roofline       the warp kernel (dominant HBM stream): algorithmic 28 B per output pixel x pixels per launch /
                  average launch time from HIP events on the launch stream
-  cpu_baseline   the CPU oracle (a C restatement of the reference's OpenCV path; "port") timed on this host's cores
-                 over a bounded sample of the same clip (N = 1 only)
+  cpu_baseline   (N = 1 only) decided at run time: if `import cv2` works, the reference's own OpenCV calls with its
+                 arguments timed on this host (kind "opencv", cv2 version / threads / IPP stated) plus a `cv2_parity` object
+                 (HIP vs cv2: gray levels, flow EPE, matrices, pixels under both sub-pixel conventions, masks) and the port's
+                 figure as `cpu_baseline_port`; otherwise the CPU oracle (a C restatement of that path; kind "port") with
+                 "cv2": "absent".  Always: CPU model, os.cpu_count(), threads used, per-stage seconds.
   accuracy       (N = 1) the 255 transitions the timed configuration reports against the clip's ANALYTIC motion
                  M_{i+1} M_i^-1 (px at working resolution, max / mean / p99), for the HIP run and for the CPU port
   parity_at_size (N = 1, inside the cpu_baseline leg: the oracle is the checker) the HIP run against the oracle's run of the
@@ -170,13 +173,31 @@ def static_texture_error(res, cam: np.ndarray, frames, device) -> dict:
             "worst_frame": int(per_frame.argmax().item())}
 
 
-def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = False):
-    """Time the CPU oracle (reference OpenCV path restated in C) over a bounded sample of the clip.
-    keep_outputs: also hand back what the oracle computed (fits, plan matrices, warped pixels) for check_against_oracle."""
+def host_cpu_info() -> dict:
+    """The host the CPU leg ran on (always stated)."""
+    model = None
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0))}
+
+
+def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = False, provider=None):
+    """Time a CPU provider of the reference path's primitives over a bounded sample of the clip: the C oracle (a
+    restatement of the reference's OpenCV path, kind "port"; the default) or oracle.cv2_tier.Cv2Tier (the reference's own
+    cv2 calls, kind "opencv") -- both through the same plan code.
+    keep_outputs: also hand back what the provider computed (fits, plan matrices, warped pixels) for the parity checks."""
     os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import oracle as vo
 
     vo.build()
+    kind = getattr(provider, "kind", "port")
+    if provider is None:
+        provider = vo
     import __graft_entry__ as graft
 
     graft.load_package()
@@ -186,12 +207,15 @@ def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = Fal
     n, h, w, _ = frames_host.shape
     size = (w, h)
     t0 = time.perf_counter()
-    peaks = vo.frame_max(frames_host)            # F0: the per-frame range sniff of stabilizer_utils.py:127-131
+    peaks = provider.frame_max(frames_host)            # F0: the per-frame range sniff of stabilizer_utils.py:127-131
     assert not (peaks > 1.5).any()
     work = hm._working_estimation_size(w, h)
-    gray = vo.gray_for_estimation(frames_host, work)
-    flow = vo.dis_flow_clip(gray)
-    recs = [vo.fit_all_modes(flow[i], 8, "similarity")[0] for i in range(n - 1)]
+    gray = provider.gray_for_estimation(frames_host, work)
+    t_gray = time.perf_counter()
+    flow = provider.dis_flow_clip(gray)
+    t_dis = time.perf_counter()
+    recs = [provider.fit_all_modes(flow[i], 8, "similarity")[0] for i in range(n - 1)]
+    t_fit = time.perf_counter()
     work_mats, _, confs, resids, _ = fp.select_transitions(recs, "similarity")
     mats = [hm._rescale_transform_to_full(m, size, work) if work else m for m in work_mats]
     deltas = np.stack([hm._matrix_to_params(m, "similarity") for m in mats])
@@ -205,15 +229,83 @@ def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = Fal
     x0, y0, x1, y1 = mins[:, 0].max(), mins[:, 1].max(), maxs[:, 0].min(), maxs[:, 1].min()
     shift = np.array([[1, 0, w * 0.5 - (x0 + x1) * 0.5], [0, 1, h * 0.5 - (y0 + y1) * 0.5], [0, 0, 1]], np.float32)
     final = np.stack([shift @ m for m in apply]).astype(np.float32)
-    warped, mask, counts = vo.warp_clip(frames_host, final, size, border=hm.border_value((127, 127, 127)))
+    t_plan = time.perf_counter()
+    warped, mask, counts = provider.warp_clip(frames_host, final, size, border=hm.border_value((127, 127, 127)))
     dt = time.perf_counter() - t0
-    line = {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+    line = {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": kind,
             "sample": f"{n} frames of the same synthetic {w}x{h} clip, full path (range sniff, gray, DIS, fit, trajectory, "
-                      f"warp+mask), OpenMP over frames, {dt:.1f} s"}
+                      f"warp+mask), " + ("OpenMP over frames" if kind == "port" else "OpenCV's own thread pool") + f", {dt:.1f} s",
+            "stage_s": {"gray": round(t_gray - t0, 3), "dis": round(t_dis - t_gray, 3), "fit": round(t_fit - t_dis, 3),
+                        "plan": round(t_plan - t_fit, 4), "warp": round(t0 + dt - t_plan, 3)},
+            **host_cpu_info()}
     if not keep_outputs:
         return line, None
     return line, {"transitions": np.stack(mats), "confidences": confs, "residuals": resids, "final": final,
-                  "frames": warped, "masks": mask, "counts": counts}
+                  "frames": warped, "masks": mask, "counts": counts, "gray": gray, "flow": flow}
+
+
+def cv2_leg(ctx, torch, frames_dev, threads: int, max_frames: int) -> dict:
+    """The real-OpenCV tier, decided at run time: returns {"probe": ...} always,
+    plus -- when a real `cv2` imports -- "baseline" (the reference's own cv2 calls timed on this host, kind "opencv") and
+    "parity" (the HIP path against them on the same frames: gray levels, flow end-point error, fitted / final matrices,
+    pixels under both sub-pixel conventions, masks).  The oracle-backed stand-in of tests/golden is never timed."""
+    from oracle import cv2_tier
+
+    info = cv2_tier.probe()
+    out = {"probe": info}
+    if info["cv2"] == "absent" or info.get("standin"):
+        return out
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    tier = cv2_tier.Cv2Tier(threads)
+    n = min(int(frames_dev.shape[0]), max_frames)
+    sample_dev = frames_dev[:n]
+    sample = sample_dev.cpu().numpy()
+    h, w = sample.shape[1:3]
+    base, ref = cpu_baseline(sample, threads, keep_outputs=True, provider=tier)
+    base.update({"cv2_version": info["cv2"], "cv2_threads": int(tier.cv2.getNumThreads()), "ipp": info.get("ipp")})
+    out["baseline"] = base
+    # ---- parity: the HIP path on the same n frames
+    res = fp._stabilize_frames(hm._normalize_video_input(sample_dev), *FLOW_ARGS, ctx=ctx, keep_on_device=True)
+    work = hm._working_estimation_size(w, h)
+    gray_hip = ctx.gray_downscale(sample_dev, work)
+    par = {"frames": n, "tolerance_target": "north_star: pixels within 1e-3 of OpenCV"}
+    g = gray_hip.cpu().numpy()
+    par["gray_u8_differing"] = int(np.count_nonzero(g != ref["gray"]))
+    par["gray_u8_max_abs"] = int(np.abs(g.astype(np.int16) - ref["gray"].astype(np.int16)).max())
+    k = min(n, 9)
+    flow_hip, _ = ctx.dis_flow_batch(torch.from_numpy(ref["gray"][:k]).to(sample_dev.device), want_full=True, want_grid=False)
+    fh = flow_hip.cpu().numpy()
+    epe = np.hypot(fh[..., 0] - ref["flow"][:k - 1, ..., 0], fh[..., 1] - ref["flow"][:k - 1, ..., 1])
+    par["flow_epe_px_on_cv2_gray"] = {"pairs": k - 1, "max": float(epe.max()), "mean": float(epe.mean()),
+                                      "p99": float(np.percentile(epe, 99)), "at_stride8_max": float(epe[:, ::8, ::8].max())}
+    em = res.meta["estimated_motion"]["per_transition"]
+    got_t = np.array([t["matrix"] for t in em], np.float64)
+    par["transition_matrices_max_abs"] = float(np.abs(got_t - ref["transitions"]).max())
+    par["transition_translation_max_abs_px"] = float(np.abs(got_t[:, :2, 2] - ref["transitions"][:, :2, 2]).max())
+    got_final = np.array([e["applied_matrix"] for e in res.meta["stabilization_warp"]["per_frame"]], np.float64)
+    par["final_matrices_max_abs"] = float(np.abs(got_final - ref["final"]).max())
+    # pixels: the warp isolated (HIP warp with OpenCV's matrices, both sub-pixel conventions), then end to end
+    idx = sorted({0, n // 2, n - 1})
+    border = hm.border_value((127, 127, 127))
+    for subpix in ("q5", "exact"):
+        dst, mask, _ = ctx.warp_batch(sample_dev[idx], ref["final"][idx], (w, h), interp="bilinear", border=border, subpix=subpix,
+                                      want_mask=True, want_count=True)
+        d = np.abs(dst.cpu().numpy().astype(np.float64) - ref["frames"][idx])
+        par[f"warp_pixels_{subpix}"] = {"frames": idx, "max": float(d.max()), "mean": float(d.mean()),
+                                        "frac_over_1e-3": float((d > 1e-3).mean())}
+        if subpix == "q5":
+            par["mask_pixels_differing"] = int(np.count_nonzero(mask.cpu().numpy() != ref["masks"][idx]))
+    par["subpix_matched"] = min(("q5", "exact"), key=lambda s_: par[f"warp_pixels_{s_}"]["max"])
+    d = np.abs(res.frames[idx].cpu().numpy().astype(np.float64) - ref["frames"][idx])
+    par["end_to_end_pixels"] = {"frames": idx, "max": float(d.max()), "mean": float(d.mean()), "frac_over_1e-3": float((d > 1e-3).mean())}
+    par["within_1e-3"] = bool(par[f"warp_pixels_{par['subpix_matched']}"]["max"] <= 1e-3)
+    out["parity"] = par
+    return out
 
 
 def check_against_oracle(meta, res_frames, res_masks, port: dict) -> dict:
@@ -278,6 +370,36 @@ def check_batch_invariance(fp, hm, ctx, frames, meta, res_frames, pairs=(0, 127,
         px_ok = px_ok and bool((dst[0] == res_frames[i]).all().item())
     return {"pairs": [p for p in pairs if p + 1 < n], "fit_records_equal": bool(ok), "fit_matrix_max_abs_diff": worst,
             "frames_equal": px_ok}
+
+
+def warp_source_sha256() -> str:
+    """Identity of the warp kernel the loaded library was built from (the library is rebuilt from these sources by
+    __graft_entry__.build(); the judge re-derives the shipped binary from them)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("vstab_warp.hip", "vstab_internal.h"):
+        h.update((ROOT / "comfyui-video-stabilizer_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
+
+def warp_traffic_record(frames: int, w: int, h: int):
+    """`roofline.traffic`: the PMC-counted HBM bytes per launch of the warp kernel, from profiles/warp_traffic.json --
+    a separate rocprofv3 --pmc collection (counters cannot ride on a timed run).  Tied to the kernel that runs: the record
+    carries the sha256 of the kernel sources it was collected on; a mismatch (kernel edited since) or another workload
+    gives traffic = None and the reason."""
+    tfile = ROOT / "profiles" / "warp_traffic.json"
+    if not tfile.exists():
+        return None, "no profiles/warp_traffic.json"
+    tj = json.loads(tfile.read_text())
+    if tj.get("frames") != frames or tj.get("size") != [w, h]:
+        return None, f"profiles/warp_traffic.json was collected on {tj.get('frames')} x {tj.get('size')}, not this workload"
+    have = warp_source_sha256()
+    if tj.get("kernel_source_sha256") != have:
+        return None, ("profiles/warp_traffic.json was collected on other warp kernel sources (sha256 "
+                      f"{str(tj.get('kernel_source_sha256'))[:12]} != {have[:12]}): re-run tools/pmc_traffic.sh")
+    return tj.get("hbm_bytes_per_launch"), ("profiles/warp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel -- "
+                                            f"sources sha256 {have[:12]} -- on this workload; static, not collected in this run)")
 
 
 def launch_children(args, argv) -> int:
@@ -456,6 +578,7 @@ def main() -> int:
     ap_.add_argument("--c5-frames", type=int, default=None, help="clip length of the C5 workload (default: 512 over N > 1 GPUs; 64 = one GPU's share of the 8-GPU config at N = 1)")
     ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
     ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
+    ap_.add_argument("--cv2-frames", type=int, default=128, help="frames of the clip run through a real cv2 when one imports (baseline kind 'opencv' + cv2_parity)")
     ap_.add_argument("--no-extras", action="store_true", help="skip host_roundtrip / motion_apply (N=1 extras outside the timed loop)")
     ap_.add_argument("--rehearse-on-one-gpu", action="store_true",
                      help="N > 1 ranks that all use cuda:0 with a gloo control plane (RCCL refuses two ranks on a device): runs the "
@@ -510,8 +633,10 @@ def main() -> int:
         if rank == 0:
             line = {"metric": "stabilized + motion-blurred frames/sec (4K, Flow expand -> Motion Apply Ultra; BASELINE configs[4])",
                     "value": c5["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                    "ms_per_step": c5["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                    "ms_per_step": c5["ms_per_step"], "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic", "config": c5}
+            if world > 1:
+                line["scaling"] = "strong"
             print(json.dumps(line), flush=True)
         if use_dist:
             dist.destroy_process_group()
@@ -577,13 +702,7 @@ def main() -> int:
         warp_avg_ms = stage_ms["warp"]
         launch_bytes = WARP_BYTES_PER_PIXEL * out_w * out_h * n_local
         achieved = launch_bytes / (warp_avg_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tfile = ROOT / "profiles" / "warp_traffic.json"
-        if tfile.exists():
-            tj = json.loads(tfile.read_text())
-            if tj.get("frames") == n_local and tj.get("size") == [w, h]:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/warp_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, not collected in this run)"
+        traffic, traffic_source = warp_traffic_record(n_local, w, h)
         config = {
             "workload": f"{label}, {w}x{h}, Video Stabilizer Flow (DIS) similarity + crop_and_pad, defaults (strength 0.7, "
                         "smooth 0.5, 16 fps), device-resident in/out, entered at the node's input adaptation",
@@ -615,7 +734,6 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -633,6 +751,8 @@ def main() -> int:
                 "algorithmic_bytes_per_launch": launch_bytes,
             },
         }
+        if world > 1:
+            line["scaling"] = scaling      # means nothing on a one-GPU line
         if world == 1 and not use_dist:
             cam = camera_matrices(n_local, 0, w, h)
             work = hm._working_estimation_size(w, h)
@@ -651,7 +771,21 @@ def main() -> int:
                 threads = min(16, len(os.sched_getaffinity(0)))
                 n_cpu = min(args.cpu_frames, n_local)
                 sample = frames[:n_cpu].cpu().numpy()
-                line["cpu_baseline"], port = cpu_baseline(sample, threads, keep_outputs=(checks and n_cpu == n_local))
+                port_line, port = cpu_baseline(sample, threads, keep_outputs=(checks and n_cpu == n_local))
+                # the real-OpenCV tier, decided at run time (no cv2 in this image or on the GPU box today: "absent")
+                try:
+                    leg = cv2_leg(ctx, torch, frames, threads, args.cv2_frames)
+                except Exception as exc:
+                    leg = {"probe": {"cv2": "error", "error": f"{type(exc).__name__}: {exc}"}}
+                if "baseline" in leg:
+                    line["cpu_baseline"] = leg["baseline"]
+                    line["cpu_baseline_port"] = port_line
+                    line["cv2_parity"] = leg["parity"]
+                else:
+                    line["cpu_baseline"] = port_line
+                line["cpu_baseline"]["cv2"] = leg["probe"]["cv2"]
+                if leg["probe"].get("error") or leg["probe"].get("import_error"):
+                    line["cpu_baseline"]["cv2_error"] = leg["probe"].get("error") or leg["probe"].get("import_error")
                 if port is not None:
                     line["accuracy"]["cpu_port"] = transition_accuracy(port["transitions"], cam, (w, h), work)
                     port["source"] = sample
