@@ -607,8 +607,21 @@ __global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_
 
 // ---- per-pixel phase bodies (shared by every launch shape) -----------------------------------
 // All indices below are GLOBAL element indices into the [P][h][w] planes; (x, y) is the pixel.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// Planes of the variational refinement, [P][h][w] each.  What a pixel's stage reads together is stored together, so that
+// one wide load replaces several dword loads: the vector-memory pipeline of a CU (address processing + L1, shared by its
+// four SIMDs) was what the tile stages waited for -- a linear-system pixel issued 18 global_load_dword, and thirteen more
+// of them cost +250 us per finest level (profiles/r04_level_kernel.md).
+//   avg, Iz   f32     0.5 (I0 + warped I1) and warped I1 - I0: the derivative phase's inputs
+//   D0, D1    float4  {Ix, Iy, Iz, Ixx} and {Ixy, Iyy, Ixz, Iyz}: the eight derivative values of the linear system
+//   UV        float2  the level's flow (u, v) as the refinement reads it (a copy of U, V made by the warp phase)
+//   dA, dB    float2  the increment (du, dv) of the fixed-point iterations, ping-pong
+// (the linear system's coefficients live in registers)
 struct VrBufs {
-    float *avg, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *tU, *tV, *dU, *dV;   // (the linear system's coefficients live in registers)
+    float *avg, *Iz;
+    f4_t *D0, *D1;
+    f2_t *UV, *dA, *dB;
 };
 
 // Plane accesses of the per-pixel phases: every pointer below is the PAIR's plane (a uniform base, SGPR pair) and every
@@ -617,10 +630,14 @@ struct VrBufs {
 __device__ __forceinline__ float ldf(const float* p, int i) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (unsigned)i * 4u); }
 __device__ __forceinline__ void stf(float* p, int i, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + (unsigned)i * 4u) = v; }
 __device__ __forceinline__ float ldb(const uint8_t* p, int i) { return (float)p[(unsigned)i]; }
+__device__ __forceinline__ f2_t ld2(const f2_t* p, int i) { return *reinterpret_cast<const f2_t*>(reinterpret_cast<const char*>(p) + (unsigned)i * 8u); }
+__device__ __forceinline__ void st2(f2_t* p, int i, f2_t v) { *reinterpret_cast<f2_t*>(reinterpret_cast<char*>(p) + (unsigned)i * 8u) = v; }
+__device__ __forceinline__ f4_t ld4(const f4_t* p, int i) { return *reinterpret_cast<const f4_t*>(reinterpret_cast<const char*>(p) + (unsigned)i * 16u); }
+__device__ __forceinline__ void st4(f4_t* p, int i, f4_t v) { *reinterpret_cast<f4_t*>(reinterpret_cast<char*>(p) + (unsigned)i * 16u) = v; }
 
 __device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ sx,
                                            const float* __restrict__ sy, float* __restrict__ U, float* __restrict__ V, int q, int i,
-                                           int j, int h, int w, int ws, int hs)
+                                           int j, int h, int w, int ws, int hs, float& u_out, float& v_out)
 {
     int end_is = i / PSTR < hs - 1 ? i / PSTR : hs - 1;
     int start_is = i - PSZ >= 0 ? (i - PSZ) / PSTR + 1 : 0;
@@ -649,15 +666,16 @@ __device__ __forceinline__ void densify_px(const uint8_t* __restrict__ I0, const
             sum_Uy += coef * syv;
             sum_coef += coef;
         }
-    stf(U, q, sum_Ux / sum_coef);
-    stf(V, q, sum_Uy / sum_coef);
+    u_out = sum_Ux / sum_coef;
+    v_out = sum_Uy / sum_coef;
+    stf(U, q, u_out);
+    stf(V, q, v_out);
 }
 
 // b: the pair's planes (VrBufs shifted to the pair, see level_kernel)
-__device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, const float* __restrict__ U,
-                                           const float* __restrict__ V, const VrBufs& b, int q, int x, int y, int h, int w)
+__device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const uint8_t* __restrict__ I1, float u, float v,
+                                           const VrBufs& b, int q, int x, int y, int h, int w)
 {
-    const float u = ldf(U, q), v = ldf(V, q);
     const float mx = x + u, my = y + v;
     const int sx = (int)__builtin_rintf(mx * 32.f), sy = (int)__builtin_rintf(my * 32.f);
     const int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
@@ -671,29 +689,31 @@ __device__ __forceinline__ void vr_warp_px(const uint8_t* __restrict__ I0, const
     const float i0 = ldb(I0, q);
     stf(b.avg, q, i0 * 0.5f + warped * 0.5f + 0.f);
     stf(b.Iz, q, warped - i0);
-    stf(b.tU, q, u);
-    stf(b.tV, q, v);
-    stf(b.dU, q, 0.f);
-    stf(b.dV, q, 0.f);
+    st2(b.UV, q, f2_t{u, v});
+    st2(b.dA, q, f2_t{0.f, 0.f});
 }
 
-__device__ __forceinline__ void vr_deriv1_px(const VrBufs& b, int q, int x, int y, int h, int w)
+// calcDerivatives of OpenCV's variational refinement for one pixel: central differences with replicated borders, first
+// order of avg and Iz, second order as the first-order operator applied to Ix / Iy -- evaluated straight from the two
+// planes everything comes from (the intermediate Ix / Iy values are recomputed at the neighbours instead of stored and
+// re-read: the same f32 subtractions of the same stored values, so the same bits) and written once, together.
+__device__ __forceinline__ void vr_deriv_px(const VrBufs& b, int q, int x, int y, int h, int w)
 {
-    const int xl = y * w + clampi(x - 1, 0, w - 1), xr = y * w + clampi(x + 1, 0, w - 1);
-    const int yu = clampi(y - 1, 0, h - 1) * w + x, yd = clampi(y + 1, 0, h - 1) * w + x;
-    stf(b.Ix, q, ldf(b.avg, xr) - ldf(b.avg, xl));
-    stf(b.Iy, q, ldf(b.avg, yd) - ldf(b.avg, yu));
-    stf(b.Ixz, q, ldf(b.Iz, xr) - ldf(b.Iz, xl));
-    stf(b.Iyz, q, ldf(b.Iz, yd) - ldf(b.Iz, yu));
-}
-
-__device__ __forceinline__ void vr_deriv2_px(const VrBufs& b, int q, int x, int y, int h, int w)
-{
-    const int xl = y * w + clampi(x - 1, 0, w - 1), xr = y * w + clampi(x + 1, 0, w - 1);
-    const int yu = clampi(y - 1, 0, h - 1) * w + x, yd = clampi(y + 1, 0, h - 1) * w + x;
-    stf(b.Ixx, q, ldf(b.Ix, xr) - ldf(b.Ix, xl));
-    stf(b.Ixy, q, ldf(b.Ix, yd) - ldf(b.Ix, yu));
-    stf(b.Iyy, q, ldf(b.Iy, yd) - ldf(b.Iy, yu));
+    const int xl = max(x - 1, 0), xr = min(x + 1, w - 1), yu = max(y - 1, 0), yd = min(y + 1, h - 1);
+    const int row = y * w, rowu = yu * w, rowd = yd * w;
+    const float* __restrict__ A = b.avg;
+    const float* __restrict__ Z = b.Iz;
+    const float Ix = ldf(A, row + xr) - ldf(A, row + xl);
+    const float Iy = ldf(A, rowd + x) - ldf(A, rowu + x);
+    const float Iz = ldf(Z, q);
+    const float Ixz = ldf(Z, row + xr) - ldf(Z, row + xl);
+    const float Iyz = ldf(Z, rowd + x) - ldf(Z, rowu + x);
+    const float Ixx = (ldf(A, row + min(xr + 1, w - 1)) - ldf(A, row + max(xr - 1, 0))) - (ldf(A, row + min(xl + 1, w - 1)) - ldf(A, row + max(xl - 1, 0)));
+    const float Ixy = (ldf(A, rowd + xr) - ldf(A, rowd + xl)) - (ldf(A, rowu + xr) - ldf(A, rowu + xl));
+    const float Iyy = (ldf(A, min(yd + 1, h - 1) * w + x) - ldf(A, max(yd - 1, 0) * w + x)) -
+                      (ldf(A, min(yu + 1, h - 1) * w + x) - ldf(A, max(yu - 1, 0) * w + x));
+    st4(b.D0, q, f4_t{Ix, Iy, Iz, Ixx});
+    st4(b.D1, q, f4_t{Ixy, Iyy, Ixz, Iyz});
 }
 
 // ---- bilinear f32 resize (flow upsampling between levels), result scaled by `mul` ------------
@@ -822,7 +842,7 @@ constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour 
 // fixed-point iteration for the temporally blocked part (tiles of an iteration are independent: they read the
 // previous iteration's increment and write the other buffer) -- with the kernel boundary as the only
 // synchronisation.  Same code, same arithmetic, same bits (tests/test_dis_gpu.py runs both).
-enum { LEVEL_FUSED = 0, LEVEL_PRE = 1, LEVEL_DERIV1 = 2, LEVEL_DERIV2 = 3, LEVEL_TILE = 4, LEVEL_MERGE = 5, LEVEL_UPSAMPLE = 6 };
+enum { LEVEL_FUSED = 0, LEVEL_PRE = 1, LEVEL_DERIV = 2, LEVEL_TILE = 4, LEVEL_MERGE = 5, LEVEL_UPSAMPLE = 6 };
 
 template <int MODE>
 __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
@@ -846,11 +866,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     const float* sy = a.Sy + (size_t)pair * a.hs * a.ws;
     // every plane shifted to this pair once (uniform: scalar registers); all accesses below are 32-bit in-plane offsets
     VrBufs b = a.vb;
-    {
-        float** planes[] = {&b.avg, &b.Iz, &b.Ix, &b.Iy, &b.Ixx, &b.Ixy, &b.Iyy, &b.Ixz, &b.Iyz, &b.tU, &b.tV, &b.dU, &b.dV};
-#pragma unroll
-        for (float** pl : planes) *pl += base;
-    }
+    b.avg += base; b.Iz += base; b.D0 += base; b.D1 += base; b.UV += base; b.dA += base; b.dB += base;
     float* __restrict__ Uw = a.U + base;   // the pair's flow at this level (densify writes it, the merge updates it)
     float* __restrict__ Vw = a.V + base;
     const float* __restrict__ U = Uw;
@@ -871,22 +887,21 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             if (x >= w) { x -= w; y++; }                                                              \
         }                                                                                             \
     }                                                                                                 \
-    if (FUSED) __syncthreads();
+    if (FUSED) __syncthreads();   /* (last line of FOR_PX: every per-pixel phase of the fused form ends in a barrier) */
     if (FUSED || MODE == LEVEL_PRE) {
-        // (a thread densifies and warps the SAME pixels, and the warp reads U,V of its own pixel only)
-        FOR_PX(densify_px(I0, I1, sx, sy, Uw, Vw, t, y, x, h, w, a.ws, a.hs))
+        // densification and the warp of the variational refinement in one pass: the warp of a pixel needs the flow of that
+        // pixel only, which the thread has just formed (no second loop over the pixels, no re-read of U / V)
+        FOR_PX(float u_, v_; densify_px(I0, I1, sx, sy, Uw, Vw, t, y, x, h, w, a.ws, a.hs, u_, v_);
+               vr_warp_px(I0, I1, u_, v_, b, t, x, y, h, w))   // also zeroes the increment (buffer A)
         FUSED_MARK(0);
-        FOR_PX(vr_warp_px(I0, I1, U, V, b, t, x, y, h, w))   // also zeroes dU/dV (increment buffer 0)
         FUSED_MARK(1);
     }
-    if (FUSED || MODE == LEVEL_DERIV1) { FOR_PX(vr_deriv1_px(b, t, x, y, h, w)) }
-    if (FUSED || MODE == LEVEL_DERIV2) { FOR_PX(vr_deriv2_px(b, t, x, y, h, w)) }
+    if (FUSED || MODE == LEVEL_DERIV) { FOR_PX(vr_deriv_px(b, t, x, y, h, w)) }
     FUSED_MARK(2);
 
-    const float* __restrict__ pIx = b.Ix;   const float* __restrict__ pIy = b.Iy;
-    const float* __restrict__ pIz = b.Iz;   const float* __restrict__ pIxx = b.Ixx;
-    const float* __restrict__ pIxy = b.Ixy; const float* __restrict__ pIyy = b.Iyy;
-    const float* __restrict__ pIxz = b.Ixz; const float* __restrict__ pIyz = b.Iyz;
+    const f4_t* __restrict__ pD0 = b.D0;
+    const f4_t* __restrict__ pD1 = b.D1;
+    const f2_t* __restrict__ pUV = b.UV;
     // LDS tile: one float4 (dU, dV, smoothness weight, pad) per padded pixel -- an update reads its own and its
     // left / up neighbours' triples with one 16-B load each and the right / down increments with one 8-B load each
     // (6 LDS instructions instead of 15), and only four loop-invariant addresses per owned pixel are live in the
@@ -901,25 +916,20 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
     // ds_write_b64 2-way.  With the pixels in raster order (round 2) the stride was 32 B: 2-way on every b128, 4-way on
     // the b64 reads and on the store -- 2.9 k of a half-sweep's 3.5 k cycles LDS-busy (profiles/r03_sor_lds_layout.md).
     // Same values, same operations, same order: same bits.
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    typedef float f2_t __attribute__((ext_vector_type(2)));
     f4_t* lP = reinterpret_cast<f4_t*>(vr_lds);
     // Plane reads of the tile stages: a uniform plane base (SGPR pair) + a 32-bit BYTE offset per lane selects the
     // `global_load_dword v, v_off, s[base]` form; indexing the float pointer instead makes the compiler widen the element
     // index to 64 bits first (one v_lshl_add_u64 per load: 36 of them in the linear-system stage).  A pair's plane has
     // fewer than 2^30 pixels (pyramid level of a <= 960-px working image; checked by the host).
 #define LDF(P, idx) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (unsigned)(idx) * 4u))
-    // increment ping-pong: (dU,dV) <-> (tU,tV) planes of the workspace
-    float* dIn_u = b.dU;  float* dIn_v = b.dV;
-    float* dOut_u = b.tU; float* dOut_v = b.tV;
+    // increment ping-pong between the two float2 planes of the workspace
+    f2_t* dIn = b.dA;
+    f2_t* dOut = b.dB;
 
     // split: one (iteration, tile) per workgroup; the increment ping-pong is a function of the iteration's parity
     const int it_lo = FUSED ? 0 : a.it, it_hi = FUSED ? VAR_ITERS : a.it + 1;
     const int tile_lo = FUSED ? 0 : part, tile_hi = FUSED ? a.tiles_x * a.tiles_y : part + 1;
-    if (!FUSED && (a.it & 1)) {
-        float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
-        tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
-    }
+    if (!FUSED && (a.it & 1)) { f2_t* tmp = dIn; dIn = dOut; dOut = tmp; }
     if (FUSED || MODE == LEVEL_TILE)
     for (int it = it_lo; it < it_hi; it++) {
         for (int tile = tile_lo; tile < tile_hi; tile++) {
@@ -934,6 +944,9 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             const int rs2 = 2 * hw;                   // LDS distance of vertical neighbours
 #define LIDX(py_, px_) ((2 * (py_) + ((px_) & 1)) * hw + ((px_) >> 1))
             // ---- stage 1: zero border, load the increment, compute the smoothness weights into LDS
+            // (Staging U + dU of the padded tile in LDS first -- two loads per pixel instead of six, the neighbours' sums
+            // from LDS -- was measured in round 4 and is slower: 316 vs 265-288 us per finest level.  This stage streams
+            // 16 B per pixel from HBM at about the CU's share of the bandwidth; its load count is not what it waits for.)
             const int s1_dy = (int)blockDim.x / pw, s1_dx = (int)blockDim.x - s1_dy * pw;
             int py = (int)threadIdx.x / pw, px = (int)threadIdx.x - py * pw;
             for (int k = threadIdx.x; k < pn; k += blockDim.x) {
@@ -942,12 +955,14 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                 if (lx >= 0 && lx < lw && ly >= 0 && ly < lh) {
                     const int gx = ox + lx, gy = oy + ly;
                     const int q = gy * w + gx;
-                    du = LDF(dIn_u, q); dv = LDF(dIn_v, q);
                     const int qr = (gx + 1 < w) ? q + 1 : q;
                     const int qd = (gy + 1 < h) ? q + w : q;
-                    const float tu = LDF(U, q) + du, tv = LDF(V, q) + dv;
-                    const float tur = LDF(U, qr) + LDF(dIn_u, qr), tvr = LDF(V, qr) + LDF(dIn_v, qr);
-                    const float tud = LDF(U, qd) + LDF(dIn_u, qd), tvd = LDF(V, qd) + LDF(dIn_v, qd);
+                    const f2_t d0 = ld2(dIn, q), dr = ld2(dIn, qr), dd = ld2(dIn, qd);
+                    const f2_t f0 = ld2(pUV, q), fr = ld2(pUV, qr), fd = ld2(pUV, qd);
+                    du = d0.x; dv = d0.y;
+                    const float tu = f0.x + du, tv = f0.y + dv;
+                    const float tur = fr.x + dr.x, tvr = fr.y + dr.y;
+                    const float tud = fd.x + dd.x, tvd = fd.y + dd.y;
                     const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
                     wv = div_plain(a.alpha2, sqrt_plain(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
                 }
@@ -982,8 +997,8 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             const int gx = ox + lx;
                             const int q = gy * w + gx;
                             const int li = LIDX(ly + 1, lx + 1), ll = LIDX(ly + 1, lx);
-                            const float Ix = LDF(pIx, q), Iy = LDF(pIy, q), Iz = LDF(pIz, q), Ixx = LDF(pIxx, q), Ixy = LDF(pIxy, q),
-                                        Iyy = LDF(pIyy, q), Ixz = LDF(pIxz, q), Iyz = LDF(pIyz, q);
+                            const f4_t e0 = ld4(pD0, q), e1 = ld4(pD1, q);
+                            const float Ix = e0.x, Iy = e0.y, Iz = e0.z, Ixx = e0.w, Ixy = e1.x, Iyy = e1.y, Ixz = e1.z, Iyz = e1.w;
                             const f4_t own = lP[li];
                             const float du = own.x, dv = own.y;
                             // The flow of the four neighbours (smoothness term, below) is requested HERE, together with the
@@ -992,9 +1007,10 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
                             // inside its `if (has_*)`: five serial memory round trips per pixel).
                             const bool has_r = gx + 1 < w, has_l = gx > 0, has_d = gy + 1 < h, has_u = gy > 0;
                             const int q_r = has_r ? q + 1 : q, q_l = has_l ? q - 1 : q, q_d = has_d ? q + w : q, q_u = has_u ? q - w : q;
-                            const float uq = LDF(U, q), vq = LDF(V, q);
-                            const float u_r = LDF(U, q_r), v_r = LDF(V, q_r), u_l = LDF(U, q_l), v_l = LDF(V, q_l);
-                            const float u_d = LDF(U, q_d), v_d = LDF(V, q_d), u_u = LDF(U, q_u), v_u = LDF(V, q_u);
+                            const f2_t fq = ld2(pUV, q), f_r = ld2(pUV, q_r), f_l = ld2(pUV, q_l), f_d = ld2(pUV, q_d), f_u = ld2(pUV, q_u);
+                            const float uq = fq.x, vq = fq.y;
+                            const float u_r = f_r.x, v_r = f_r.y, u_l = f_l.x, v_l = f_l.y;
+                            const float u_d = f_d.x, v_d = f_d.y, u_u = f_u.x, v_u = f_u.y;
                             const float wl = lP[ll].z, wu = lP[li - rs2].z;
                             float a11, a12, a22, B1, B2;
                             {
@@ -1099,9 +1115,7 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
                 const int gx = ix0 + xx, gy = iy0 + yy;
                 const int li = LIDX(gy - oy + 1, gx - ox + 1);
-                const f2_t uv = *reinterpret_cast<const f2_t*>(lP + li);
-                dOut_u[gy * w + gx] = uv.x;
-                dOut_v[gy * w + gx] = uv.y;
+                st2(dOut, gy * w + gx, *reinterpret_cast<const f2_t*>(lP + li));
                 xx += s4_dx; yy += s4_dy;
                 if (xx >= iw) { xx -= iw; yy++; }
             }
@@ -1109,15 +1123,15 @@ __global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
             FUSED_MARK(6);
 #undef LIDX
         }
-        float* tmp = dIn_u; dIn_u = dOut_u; dOut_u = tmp;
-        tmp = dIn_v; dIn_v = dOut_v; dOut_v = tmp;
+        f2_t* tmp = dIn; dIn = dOut; dOut = tmp;
     }
     // mergeCheckerboard(W, tempW): W + dW of the last fixed-point iteration
-    if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) { dIn_u = b.tU; dIn_v = b.tV; }   // where iteration VAR_ITERS-1 wrote
+    if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) dIn = b.dB;   // where iteration VAR_ITERS-1 wrote
     if (FUSED || MODE == LEVEL_MERGE) {
         for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {
-            stf(Uw, q_, ldf(U, q_) + ldf(dIn_u, q_));
-            stf(Vw, q_, ldf(V, q_) + ldf(dIn_v, q_));
+            const f2_t f = ld2(pUV, q_), d = ld2(dIn, q_);
+            stf(Uw, q_, f.x + d.x);
+            stf(Vw, q_, f.y + d.y);
         }
         if (FUSED) __syncthreads();
     }
@@ -1269,8 +1283,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         aux = c.take<float>(5 * (size_t)n * F.h * F.ws);
         Sx = c.take<float>((size_t)P * F.hs * F.ws);
         Sy = c.take<float>((size_t)P * F.hs * F.ws);
-        float** planes[] = {&vb.avg, &vb.Iz, &vb.Ix, &vb.Iy, &vb.Ixx, &vb.Ixy, &vb.Iyy, &vb.Ixz, &vb.Iyz, &vb.tU, &vb.tV, &vb.dU, &vb.dV};
-        for (float** pl : planes) *pl = c.take<float>(npF);
+        vb.avg = c.take<float>(npF); vb.Iz = c.take<float>(npF);
+        vb.D0 = c.take<f4_t>(npF); vb.D1 = c.take<f4_t>(npF);
+        vb.UV = c.take<f2_t>(npF); vb.dA = c.take<f2_t>(npF); vb.dB = c.take<f2_t>(npF);
     };
     {
         Carver sizer(nullptr);
@@ -1391,8 +1406,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             const int px_parts = std::max(1, std::min(64, (g.h * g.w + FUSED_T - 1) / FUSED_T));
             la.parts = px_parts;
             hipLaunchKernelGGL(level_kernel<LEVEL_PRE>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
-            hipLaunchKernelGGL(level_kernel<LEVEL_DERIV1>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
-            hipLaunchKernelGGL(level_kernel<LEVEL_DERIV2>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
+            hipLaunchKernelGGL(level_kernel<LEVEL_DERIV>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
             if (vr_lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_kernel<LEVEL_TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
             la.parts = la.tiles_x * la.tiles_y;
