@@ -500,24 +500,51 @@ __global__ __launch_bounds__(64 * PIS4_WAVES * PIS_STRIPES_PER_BLOCK) void pis4_
                 // produced it) may differ between the passes, so wait for the forward pass of every row of the group
                 for (int q = 0; q < nq; q++) wait_progress(done0 + (row_a + dir * q), ws, spin_budget, a.status);
             }
+            // A step's inputs from memory (the lane's four I0 pixels and gradients, the patch's structure tensor and, in the
+            // forward pass, its initial flow) depend on the patch position only, never on what the search computes: they
+            // are requested ONE STEP AHEAD, before the current step's descent starts, so their L2 / HBM round trip runs
+            // under the ~10^4 cycles of dependent arithmetic of a step instead of at the head of the next one (the kernel
+            // has two wavefronts per SIMD and nothing else to hide it behind).
+            struct StepIn { uint8_t i[4]; short gx[4], gy[4]; float t[5], u0, v0; };
+            auto fetch = [&](int visited_) {
+                StepIn r;
+                const int js_ = start_js + dir * visited_;
+                const int j_ = js_ * PSTR;
+                const int sidx_ = is * ws + js_;
+                const size_t p0 = (size_t)(i + 2 * rr) * w + j_ + c2, p1 = p0 + w;   // patch rows 2rr, 2rr+1; columns c2, c2+4
+                r.i[0] = I0[p0]; r.i[1] = I0[p0 + 4]; r.i[2] = I0[p1]; r.i[3] = I0[p1 + 4];
+                r.gx[0] = Ix[p0]; r.gx[1] = Ix[p0 + 4]; r.gx[2] = Ix[p1]; r.gx[3] = Ix[p1 + 4];
+                r.gy[0] = Iy[p0]; r.gy[1] = Iy[p0 + 4]; r.gy[2] = Iy[p1]; r.gy[3] = Iy[p1 + 4];
+#pragma unroll
+                for (int c = 0; c < 5; c++) r.t[c] = T[c * tplane + sidx_];
+                r.u0 = r.v0 = 0.f;
+                if (iter == 0) {
+                    r.u0 = U[(size_t)(i + PSZ / 2) * w + j_ + PSZ / 2];
+                    r.v0 = V[(size_t)(i + PSZ / 2) * w + j_ + PSZ / 2];
+                }
+                return r;
+            };
+            StepIn nxt{};
+            if (row_ok && Q == 0) nxt = fetch(0);                      // step 0: only the leading row is active
             for (int s = 0; s < ws + nq - 1; s++) {
                 const int visited = s - Q;                             // patches this row finished before this step
                 const bool act = row_ok && visited >= 0 && visited < ws;
+                const StepIn cur = nxt;
+                if (row_ok && visited + 1 >= 0 && visited + 1 < ws) nxt = fetch(visited + 1);
                 if (k > 0 && s < ws) wait_progress(done + (row_a - dir), s + 1, spin_budget, a.status);   // leading row's vertical neighbour (previous group)
                 if (act) {
                     const int js = start_js + dir * visited;
                     const int j = js * PSTR;
                     const int sidx = is * ws + js;
-                    const size_t p0 = (size_t)(i + 2 * rr) * w + j + c2, p1 = p0 + w;   // patch rows 2rr, 2rr+1; columns c2, c2+4
-                    const float i00 = (float)I0[p0], i01 = (float)I0[p0 + 4], i10 = (float)I0[p1], i11 = (float)I0[p1 + 4];
-                    const float gx00 = (float)Ix[p0], gx01 = (float)Ix[p0 + 4], gx10 = (float)Ix[p1], gx11 = (float)Ix[p1 + 4];
-                    const float gy00 = (float)Iy[p0], gy01 = (float)Iy[p0 + 4], gy10 = (float)Iy[p1], gy11 = (float)Iy[p1 + 4];
-                    const float txx = T[sidx], tyy = T[tplane + sidx], txy = T[2 * tplane + sidx];
-                    const float x_grad_sum = T[3 * tplane + sidx], y_grad_sum = T[4 * tplane + sidx];
+                    const float i00 = (float)cur.i[0], i01 = (float)cur.i[1], i10 = (float)cur.i[2], i11 = (float)cur.i[3];
+                    const float gx00 = (float)cur.gx[0], gx01 = (float)cur.gx[1], gx10 = (float)cur.gx[2], gx11 = (float)cur.gx[3];
+                    const float gy00 = (float)cur.gy[0], gy01 = (float)cur.gy[1], gy10 = (float)cur.gy[2], gy11 = (float)cur.gy[3];
+                    const float txx = cur.t[0], tyy = cur.t[1], txy = cur.t[2];
+                    const float x_grad_sum = cur.t[3], y_grad_sum = cur.t[4];
                     float Sxv, Syv;
                     if (iter == 0) {
-                        Sxv = U[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
-                        Syv = V[(size_t)(i + PSZ / 2) * w + j + PSZ / 2];
+                        Sxv = cur.u0;
+                        Syv = cur.v0;
                     } else {
                         Sxv = lSx[sidx];
                         Syv = lSy[sidx];
