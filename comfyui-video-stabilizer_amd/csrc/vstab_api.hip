@@ -43,28 +43,7 @@ void ScratchBuf::release()
     bytes = 0;
 }
 
-bool vstab_invert3x3(const double* S, double* D)
-{
-    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
-               S[2] * (S[3] * S[7] - S[4] * S[6]);
-    if (d == 0.0) {
-        for (int i = 0; i < 9; i++) D[i] = 0.0;
-        return false;
-    }
-    d = 1.0 / d;
-    double t[9];
-    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
-    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
-    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
-    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
-    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
-    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
-    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
-    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
-    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
-    for (int i = 0; i < 9; i++) D[i] = t[i];
-    return true;
-}
+bool vstab_invert3x3(const double* S, double* D) { return vstab_invert3x3_hd(S, D); }
 
 int vstab_stage_params(vstab_ctx* ctx, const void* host, size_t bytes, void** dev_out)
 {
@@ -164,6 +143,10 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->h_fit.release();
     ctx->d_gray_tmp.release();
     ctx->d_range.release();
+    ctx->d_plan.release();
+    ctx->h_plan.release();
+    if (ctx->ev_fit_done) (void)hipEventDestroy(ctx->ev_fit_done);
+    if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
     for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
     if (ctx->h_status) (void)hipHostFree(const_cast<int*>(ctx->h_status));

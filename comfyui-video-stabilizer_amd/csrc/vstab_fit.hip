@@ -418,6 +418,9 @@ __global__ __launch_bounds__(FIT_THREADS) void fit_kernel(FitArgs a)
 int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
                          int cap, vstab_fit_record* d_out);
 
+// results == nullptr: launch only -- the records stay on the device (vstab_fit_records_device), their download is queued
+// behind the kernels with an event, and vstab_sample_fit_batch_end collects it (the speculative plan and the warp are
+// queued in between, flow_pipeline.py).
 static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pairs, int gh, int gw, int step, int cap,
                    int requested_mode, vstab_fit_record* results)
 {
@@ -439,6 +442,12 @@ static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pai
         }
     }
     VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (results == nullptr) {
+        if (!ctx->ev_fit_done) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_fit_done, hipEventDisableTiming));
+        VSTAB_HIP(hipEventRecord(ctx->ev_fit_done, ctx->stream));
+        ctx->fit_pairs_pending = pairs;
+        return 0;
+    }
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(results, ctx->h_fit.ptr, rec_bytes);
     // the flow these fits were computed from was produced asynchronously by vstab_dis_flow_batch on the same stream:
@@ -455,6 +464,33 @@ extern "C" int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, in
     VSTAB_REQUIRE(requested_mode >= VSTAB_MODE_TRANSLATION && requested_mode <= VSTAB_MODE_PERSPECTIVE, "vstab_sample_fit_batch: unknown mode %d", requested_mode);
     VSTAB_REQUIRE((long long)gh * gw <= MAX_SORT, "vstab_sample_fit_batch: %d sample points exceed the supported %d", gh * gw, MAX_SORT);
     return run_fit(ctx, grid_flow, nullptr, pairs, gh, gw, step, gh * gw, requested_mode, results);
+}
+
+extern "C" int vstab_sample_fit_batch_begin(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw, int step,
+                                            int requested_mode)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_sample_fit_batch_begin: ctx is NULL");
+    VSTAB_REQUIRE(grid_flow != nullptr, "vstab_sample_fit_batch_begin: NULL pointer argument");
+    VSTAB_REQUIRE(pairs > 0 && gh > 0 && gw > 0 && step > 0, "vstab_sample_fit_batch_begin: non-positive size");
+    VSTAB_REQUIRE(requested_mode >= VSTAB_MODE_TRANSLATION && requested_mode <= VSTAB_MODE_PERSPECTIVE, "vstab_sample_fit_batch_begin: unknown mode %d", requested_mode);
+    VSTAB_REQUIRE((long long)gh * gw <= MAX_SORT, "vstab_sample_fit_batch_begin: %d sample points exceed the supported %d", gh * gw, MAX_SORT);
+    return run_fit(ctx, grid_flow, nullptr, pairs, gh, gw, step, gh * gw, requested_mode, nullptr);
+}
+
+extern "C" const vstab_fit_record* vstab_fit_records_device(vstab_ctx* ctx)
+{
+    return (ctx && ctx->fit_pairs_pending > 0) ? static_cast<const vstab_fit_record*>(ctx->d_fit.ptr) : nullptr;
+}
+
+extern "C" int vstab_sample_fit_batch_end(vstab_ctx* ctx, int pairs, vstab_fit_record* results)
+{
+    VSTAB_REQUIRE(ctx != nullptr && results != nullptr, "vstab_sample_fit_batch_end: NULL argument");
+    VSTAB_REQUIRE(ctx->fit_pairs_pending > 0 && pairs == ctx->fit_pairs_pending, "vstab_sample_fit_batch_end: no fit of %d pairs is pending", pairs);
+    VSTAB_HIP(hipEventSynchronize(ctx->ev_fit_done));
+    memcpy(results, ctx->h_fit.ptr, sizeof(vstab_fit_record) * (size_t)pairs * 3);
+    ctx->fit_pairs_pending = 0;
+    // the event lies behind the DIS kernels of the same stream: a device-side failure report of theirs has landed
+    return vstab_check_device_status(ctx, "vstab_sample_fit_batch_end");
 }
 
 extern "C" int vstab_points_fit_batch(vstab_ctx* ctx, const float* point_pairs, const int* counts, int pairs, int max_points,

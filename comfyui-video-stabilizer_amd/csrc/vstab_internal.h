@@ -67,6 +67,11 @@ struct vstab_ctx {
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_xfer_sync = nullptr;
     hipStream_t xfer_stream = nullptr;
+    // speculative device-side plan (vstab_plan.hip): the plan's outputs on the device (final float32 matrices, warp
+    // table, path / target) and their pinned host copy, an event behind each asynchronous download
+    ScratchBuf d_plan, h_plan;
+    hipEvent_t ev_fit_done = nullptr, ev_plan_done = nullptr;
+    int fit_pairs_pending = 0, plan_frames = 0, plan_params = 0;
     // DIS: the per-level image preparation (pad, gradients, structure tensor) runs on its own stream beside the
     // coarse-to-fine chain, one event per pyramid level (vstab_dis.hip)
     hipStream_t prep_stream = nullptr;
@@ -107,5 +112,50 @@ struct KernelTimer {
     }
 };
 
-// cv::invert for a 3x3 CV_64F matrix (closed form); returns false (and zeros) if singular.
+// cv::invert for a 3x3 CV_64F matrix (closed form); returns false (and zeros) if singular.  One definition for the host
+// (vstab_warp_batch inverts the caller's matrices) and the device (plan_kernel writes the warp's table itself): IEEE fp64
+// operations in one fixed order, no contraction (-ffp-contract=off), so both produce the same bits.
+__host__ __device__ inline bool vstab_invert3x3_hd(const double* S, double* D)
+{
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+               S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d == 0.0) {
+        for (int i = 0; i < 9; i++) D[i] = 0.0;
+        return false;
+    }
+    d = 1.0 / d;
+    double t[9];
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    for (int i = 0; i < 9; i++) D[i] = t[i];
+    return true;
+}
 bool vstab_invert3x3(const double* S, double* D);
+
+// The warp kernels' per-(frame, sample) transform record and how it is filled from a float32 matrix
+// (cv::warpPerspective: M.convertTo(CV_64F), invert).
+struct WarpXform {
+    double m[9];     // inverse (output -> source) matrix, as cv::warpPerspective builds it
+    double wq;       // affine only: m8 ? 32/m8 : 0
+    double wn;       // affine only: m8 ? 1/m8 : 0
+    int affine;      // m6 == 0 && m7 == 0
+    int pad_;
+};
+__host__ __device__ inline void vstab_fill_xform(const float* m32, WarpXform* xf)
+{
+    double M[9];
+    for (int i = 0; i < 9; i++) M[i] = (double)m32[i];
+    vstab_invert3x3_hd(M, xf->m);
+    xf->affine = (xf->m[6] == 0.0 && xf->m[7] == 0.0) ? 1 : 0;
+    const double W = xf->m[8];
+    xf->wq = (W != 0.0) ? 32.0 / W : 0.0;
+    xf->wn = (W != 0.0) ? 1.0 / W : 0.0;
+    xf->pad_ = 0;
+}

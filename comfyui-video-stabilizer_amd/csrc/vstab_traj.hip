@@ -1,91 +1,251 @@
-// vstab_traj.hip -- F7+F8: camera path (prefix sum), box-filter smoothing and strength blend, fp64.
+// vstab_traj.hip -- F6-F12: from the per-pair candidate fits to the warp's transform table.
 //
-// Replaces nodes/video_stabilizer_flow.py:356-371 and nodes/stabilizer_utils.py:361-383
-// (_smooth_path: symmetric moving average, window derived from fps, edge padding).  The work is
-// O(N*P*window) on a few thousand doubles: one block, one lane per (column, output row); the
-// prefix sum is the sequential recurrence of the reference (path[i] = path[i-1] + delta[i]).
+//   vstab_trajectory        F7+F8 on the HOST: camera path (prefix sum), box-filter smoothing and strength blend, fp64
+//                           (nodes/video_stabilizer_flow.py:356-371, nodes/stabilizer_utils.py:361-383: symmetric moving
+//                           average, window derived from fps, edge padding).  A few thousand doubles: the host loop takes
+//                           microseconds, a kernel cost two transfers and a synchronisation in the middle of the plan.
+//   vstab_flow_plan_device  the WHOLE plan of a crop_and_pad clip on the device, speculatively: sticky-mode walk
+//                           (flow.py:324-339), rescale + parameter deltas (flow.py:340-346), path / smoothing / blend,
+//                           parameters -> float32 matrices (stabilizer_utils.py:327-358), bounding boxes and the common
+//                           region (stabilizer_utils.py:1010-1034, flow.py:500-504), recentring shift and final = T @ M
+//                           (flow.py:505-521), inverted into the warp kernels' table -- one small fp64 kernel behind the fit
+//                           kernel on the same stream, so the warp starts without a host round trip.
+//
+// Why "speculatively": the reference forms atan2 / log / exp / cos / sin with Python's math module, i.e. the HOST's libm,
+// and the reported motion (path, target_path, applied_matrix in the meta) must equal what it computes.  The device's fp64
+// math library is not glibc's: it may differ in the last unit of a double, which survives the float32 cast of a matrix
+// entry with probability ~1e-8.  So the host still computes the plan exactly (while the warp runs -- it needs the fit
+// records for the meta anyway) and compares its float32 final matrices with the device's, bit for bit; a frame whose
+// matrices differ is warped again with the host's matrix (flow_pipeline.py).  The outputs are therefore always those of
+// the host plan; the device plan only removes the wait.  Models with a perspective row are not speculated on: their
+// final = T @ M has two-term sums whose float32 rounding depends on NumPy's BLAS (fused or not).
 #include "vstab_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
-__global__ __launch_bounds__(256) void trajectory_kernel(const double* __restrict__ deltas, double* __restrict__ path,
-                                                         double* __restrict__ target, int n, int p, int window, int do_smooth,
-                                                         double strength, int camera_lock)
+constexpr int PLAN_T = 1024;
+constexpr size_t PLAN_LDS_MAX = 144 * 1024;
+
+struct PlanArgs {
+    const vstab_fit_record* rec;   // [pairs][3], indexed [pair][mode]
+    int pairs, mode;               // requested model: VSTAB_MODE_TRANSLATION | VSTAB_MODE_SIMILARITY
+    int rescale;                   // 1: F = f32(fl(up_i * M_ij) * down_j), 0: F = M
+    double up[3], down[3];
+    int window, do_smooth, camera_lock;
+    double strength, width, height;
+    float* final32;                // [frames][9]
+    WarpXform* xf;                 // [frames]
+    double* path;                  // [frames][p]
+    double* target;                // [frames][p]
+    double* region;                // [4]: x0, y0, x1, y1 of the common region (tests)
+    int perturb;                   // tests (VSTAB_DEBUG_PLAN_PERTURB=frame): that frame's matrix is made wrong by one ulp
+};
+
+__device__ __forceinline__ double np_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+__device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+
+// block-wide reduction of four doubles (max, max, min, min) with NumPy's NaN-propagating minimum / maximum
+__device__ void reduce_region(double v[4], double* s_red /*[4][PLAN_T / 64]*/)
 {
-    // phase 1: sequential prefix sum per column
-    if (threadIdx.x < p) {
-        const int c = threadIdx.x;
-        double acc = 0.0;
-        path[c] = 0.0;
-        for (int i = 1; i < n; i++) {
-            acc = acc + deltas[(size_t)(i - 1) * p + c];
-            path[(size_t)i * p + c] = acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        v[0] = np_max(v[0], __shfl_xor(v[0], off)); v[1] = np_max(v[1], __shfl_xor(v[1], off));
+        v[2] = np_min(v[2], __shfl_xor(v[2], off)); v[3] = np_min(v[3], __shfl_xor(v[3], off));
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = PLAN_T / 64;
+    if (lane == 0) for (int k = 0; k < 4; k++) s_red[k * nw + wave] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 4; k++) {
+            double acc = s_red[k * nw];
+            for (int i = 1; i < nw; i++) acc = k < 2 ? np_max(acc, s_red[k * nw + i]) : np_min(acc, s_red[k * nw + i]);
+            s_red[k * nw] = acc;
         }
     }
     __syncthreads();
-    // phase 2: moving average over the edge-padded series, then blend
-    const int pad = window / 2;
-    const double kv = 1.0 / (double)window;
-    for (int t = threadIdx.x; t < n * p; t += blockDim.x) {
-        const int i = t / p, c = t - i * p;
-        const double cur = path[t];
-        double sm = cur;
-        if (do_smooth) {
-            double acc = 0.0;
-            for (int k = 0; k < window; k++) {
-                int s = i + k - pad;
-                s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
-                acc += path[(size_t)s * p + c] * kv;
-            }
-            sm = acc;
-        }
-        target[t] = camera_lock ? 0.0 : cur + strength * (sm - cur);
-    }
+    for (int k = 0; k < 4; k++) v[k] = s_red[k * nw];
 }
 
-// Same arithmetic with the path held in LDS (n*p doubles): the deltas arrive with one coalesced pass, the sequential
-// prefix sums (one lane per parameter, fixed order) run on LDS latency instead of a global load/store per frame, and
-// the window sums read LDS.  Used whenever the path fits (multi-GPU runs smooth the whole clip on every rank).
-constexpr int TRAJ_T = 1024;
-constexpr size_t TRAJ_LDS_MAX = 144 * 1024;
-
-__global__ __launch_bounds__(TRAJ_T) void trajectory_lds_kernel(const double* __restrict__ deltas, double* __restrict__ path,
-                                                                double* __restrict__ target, int n, int p, int window, int do_smooth,
-                                                                double strength, int camera_lock)
+// One workgroup.  LDS: the path [frames][p] fp64 (as the former trajectory kernel held it), the chosen mode per pair, and
+// the reduction scratch.
+__global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
 {
     extern __shared__ double s_path[];
-    const int total = n * p;
-    for (int t = threadIdx.x; t < total; t += TRAJ_T) s_path[t] = t < p ? 0.0 : deltas[t - p];
+    const int p = a.mode == VSTAB_MODE_SIMILARITY ? 4 : 2;
+    const int frames = a.pairs + 1, total = frames * p;
+    double* s_red = s_path + total;                                  // [4][PLAN_T / 64]
+    signed char* s_mode = reinterpret_cast<signed char*>(s_red + 4 * (PLAN_T / 64));   // [pairs]
+
+    // ---- sticky active_mode walk (flow.py:324-339 + 153-210).  Sequential as written, but the active mode only ever
+    // steps DOWN (it becomes the mode that was used), and below similarity there is only translation: with `first` = the
+    // first pair whose similarity fit is unusable, every pair before it uses similarity and every pair from it on uses
+    // translation if that fit is usable, else nothing (identity, reported as "translation", and the active mode stays at
+    // translation).  One block-wide minimum instead of a pair-by-pair walk of one lane through global memory (measured:
+    // ~0.2 ms for 255 pairs, most of what the device plan was meant to save).
+    __shared__ int s_first;
+    if (threadIdx.x == 0) s_first = a.pairs;
     __syncthreads();
+    if (a.mode == VSTAB_MODE_SIMILARITY) {
+        int mine = a.pairs;
+        for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
+            const vstab_fit_record& r = a.rec[(size_t)i * 3 + VSTAB_MODE_SIMILARITY];
+            if (!(r.computed != 0 && r.accepted != 0)) { mine = i; break; }   // this thread's pairs ascend
+        }
+        if (mine < a.pairs) atomicMin(&s_first, mine);
+    } else if (threadIdx.x == 0) {
+        s_first = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
+        int pick = VSTAB_MODE_SIMILARITY;
+        if (i >= s_first) {
+            const vstab_fit_record& r = a.rec[(size_t)i * 3 + VSTAB_MODE_TRANSLATION];
+            pick = (r.computed != 0 && r.accepted != 0) ? VSTAB_MODE_TRANSLATION : -1;
+        }
+        s_mode[i] = (signed char)pick;
+    }
+    __syncthreads();
+    // ---- rescale to full resolution + parameter deltas of the REQUESTED model (flow.py:340-346), into the path array
+    for (int t = threadIdx.x; t < p; t += PLAN_T) s_path[t] = 0.0;
+    for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
+        float M[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        const int pick = s_mode[i];
+        if (pick >= 0) {
+            const float* src = a.rec[(size_t)i * 3 + pick].matrix;
+            for (int k = 0; k < 9; k++) M[k] = src[k];
+        }
+        float F[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                if (a.rescale) {
+                    const double t = a.up[r] * (double)M[r * 3 + c];
+                    F[r * 3 + c] = (float)(t * a.down[c]);
+                } else {
+                    F[r * 3 + c] = M[r * 3 + c];
+                }
+            }
+        double* P = s_path + (size_t)(i + 1) * p;
+        P[0] = (double)F[2]; P[1] = (double)F[5];
+        if (a.mode == VSTAB_MODE_SIMILARITY) {
+            const float fa = F[0], fc = F[3];
+            const float aa = fa * fa, cc = fc * fc;
+            const float sq = aa + cc;
+            const double sq64 = (1e-10f > sq) ? 1e-10 : (double)sq;
+            P[2] = atan2((double)fc, (double)fa);
+            P[3] = log(sqrt(sq64));
+        }
+    }
+    __syncthreads();
+    // ---- path = prefix sum of the deltas (flow.py:356-358), one lane per parameter, in order
     if ((int)threadIdx.x < p) {
         const int c = threadIdx.x;
         double acc = 0.0;
 #pragma unroll 8
-        for (int i = 1; i < n; i++) {
+        for (int i = 1; i < frames; i++) {
             acc = acc + s_path[i * p + c];
             s_path[i * p + c] = acc;
         }
     }
     __syncthreads();
-    const int pad = window / 2;
-    const double kv = 1.0 / (double)window;
-    for (int t = threadIdx.x; t < total; t += TRAJ_T) {
-        const int i = t / p, c = t - i * p;
-        const double cur = s_path[t];
-        double sm = cur;
-        if (do_smooth) {
-            double acc = 0.0;
-            for (int k = 0; k < window; k++) {
-                int s = i + k - pad;
-                s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
-                acc += s_path[s * p + c] * kv;
+    // ---- per frame: smoothed target, correction, float32 matrix, corners (same arithmetic as vstab_trajectory /
+    //      vstab_params_to_matrices / vstab_bounding_boxes on the host)
+    const int pad = a.window / 2;
+    const double kv = 1.0 / (double)a.window;
+    double reg[4] = {-INFINITY, -INFINITY, INFINITY, INFINITY};   // max of mins.x, mins.y; min of maxs.x, maxs.y
+    float A[9];
+    for (int i = threadIdx.x; i < frames; i += PLAN_T) {
+        double diff[4];
+        for (int c = 0; c < p; c++) {
+            const double cur = s_path[i * p + c];
+            double sm = cur;
+            if (a.do_smooth) {
+                double acc = 0.0;
+                for (int k = 0; k < a.window; k++) {
+                    int s = i + k - pad;
+                    s = s < 0 ? 0 : (s > frames - 1 ? frames - 1 : s);
+                    acc += s_path[s * p + c] * kv;
+                }
+                sm = acc;
             }
-            sm = acc;
+            const double tgt = a.camera_lock ? 0.0 : cur + a.strength * (sm - cur);
+            a.path[(size_t)i * p + c] = cur;
+            a.target[(size_t)i * p + c] = tgt;
+            diff[c] = tgt - cur;
         }
-        path[t] = cur;
-        target[t] = camera_lock ? 0.0 : cur + strength * (sm - cur);
+        if (a.mode == VSTAB_MODE_SIMILARITY) {
+            const double s = exp(diff[3]), ct = cos(diff[2]), st = sin(diff[2]);
+            const double sc = s * ct, ss = s * st;
+            A[0] = (float)sc; A[1] = (float)(-ss); A[2] = (float)diff[0];
+            A[3] = (float)ss; A[4] = (float)sc; A[5] = (float)diff[1];
+        } else {
+            A[0] = 1.f; A[1] = 0.f; A[2] = (float)diff[0];
+            A[3] = 0.f; A[4] = 1.f; A[5] = (float)diff[1];
+        }
+        A[6] = 0.f; A[7] = 0.f; A[8] = 1.f;
+        for (int k = 0; k < 9; k++) a.final32[(size_t)i * 9 + k] = A[k];   // the apply matrix, recentred below
+        const double cx[4] = {0.0, a.width, 0.0, a.width}, cy[4] = {0.0, 0.0, a.height, a.height};
+        double xs[4], ys[4];
+        for (int j = 0; j < 4; j++) {
+            double q[3];
+            for (int r = 0; r < 3; r++) {
+                const double t0 = (double)A[r * 3 + 0] * cx[j];
+                const double t1 = (double)A[r * 3 + 1] * cy[j];
+                const double t2 = (double)A[r * 3 + 2] * 1.0;
+                q[r] = (t0 + t1) + t2;
+            }
+            xs[j] = q[0] / q[2];
+            ys[j] = q[1] / q[2];
+        }
+        reg[0] = np_max(reg[0], np_min(np_min(xs[0], xs[1]), np_min(xs[2], xs[3])));
+        reg[1] = np_max(reg[1], np_min(np_min(ys[0], ys[1]), np_min(ys[2], ys[3])));
+        reg[2] = np_min(reg[2], np_max(np_max(xs[0], xs[1]), np_max(xs[2], xs[3])));
+        reg[3] = np_min(reg[3], np_max(np_max(ys[0], ys[1]), np_max(ys[2], ys[3])));
     }
+    // ---- common region over all frames -> recentring shift (flow.py:501-511), float32 like the reference's matrix
+    reduce_region(reg, s_red);
+    if (threadIdx.x == 0) for (int k = 0; k < 4; k++) a.region[k] = reg[k];
+    const float off_x = (float)(a.width * 0.5 - (reg[0] + reg[2]) * 0.5);
+    const float off_y = (float)(a.height * 0.5 - (reg[1] + reg[3]) * 0.5);
+    // ---- final = T @ A in float32 (A is affine: every sum has one inexact term), inverted into the warp's table
+    for (int i = threadIdx.x; i < frames; i += PLAN_T) {
+        float* Fm = a.final32 + (size_t)i * 9;
+        float R[9];
+        for (int c = 0; c < 3; c++) {
+            R[c] = (1.f * Fm[c] + 0.f * Fm[3 + c]) + off_x * Fm[6 + c];
+            R[3 + c] = (0.f * Fm[c] + 1.f * Fm[3 + c]) + off_y * Fm[6 + c];
+            R[6 + c] = (0.f * Fm[c] + 0.f * Fm[3 + c]) + 1.f * Fm[6 + c];
+        }
+        if (i == a.perturb) R[2] = __uint_as_float(__float_as_uint(R[2]) + 1u);   // a disagreement for the verification to catch
+        for (int k = 0; k < 9; k++) Fm[k] = R[k];
+        vstab_fill_xform(R, a.xf + i);
+    }
+}
+
+int smoothing_window(double smooth, double fps)   // stabilizer_utils.py:363-375
+{
+    fps = fps > 1.0 ? fps : 1.0;
+    const double min_seconds = 3.0 / 16.0, max_seconds = 13.0 / 16.0;
+    const double window_seconds = min_seconds + smooth * (max_seconds - min_seconds);
+    int window = (int)std::nearbyint(window_seconds * fps);  // Python round(): half to even
+    window = window > 3 ? window : 3;
+    if (window % 2 == 0) window += 1;
+    return window;
+}
+
+struct PlanLayout { size_t final32, xf, path, target, region, total; };
+PlanLayout plan_layout(int frames, int p)
+{
+    PlanLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~size_t(255); return o; };
+    L.final32 = take(sizeof(float) * 9 * (size_t)frames);
+    L.path = take(sizeof(double) * (size_t)frames * p);
+    L.target = take(sizeof(double) * (size_t)frames * p);
+    L.region = take(sizeof(double) * 4);
+    L.xf = take(sizeof(WarpXform) * (size_t)frames);
+    L.total = off;
+    return L;
 }
 
 }  // namespace
@@ -93,42 +253,107 @@ __global__ __launch_bounds__(TRAJ_T) void trajectory_lds_kernel(const double* __
 extern "C" int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double smooth, double fps,
                                 double strength, int camera_lock, double* path, double* target)
 {
-    VSTAB_REQUIRE(ctx != nullptr, "vstab_trajectory: ctx is NULL");
+    (void)ctx;   // host arithmetic (kept in the signature: the entry point predates the host form)
     VSTAB_REQUIRE(deltas && path && target, "vstab_trajectory: NULL pointer argument");
     VSTAB_REQUIRE(n >= 2 && p >= 1 && p <= 8, "vstab_trajectory: unsupported shape n=%d p=%d", n, p);
-    VSTAB_HIP(hipSetDevice(ctx->device));
-    // stabilizer_utils.py:363-375
     smooth = smooth < 0.0 ? 0.0 : (smooth > 1.0 ? 1.0 : smooth);
     strength = strength < 0.0 ? 0.0 : (strength > 1.0 ? 1.0 : strength);
     const int do_smooth = !(smooth <= 0.0 || n <= 2);
-    fps = fps > 1.0 ? fps : 1.0;
-    const double min_seconds = 3.0 / 16.0, max_seconds = 13.0 / 16.0;
-    const double window_seconds = min_seconds + smooth * (max_seconds - min_seconds);
-    int window = (int)std::nearbyint(window_seconds * fps);  // Python round(): half to even
-    window = window > 3 ? window : 3;
-    if (window % 2 == 0) window += 1;
-
-    const size_t in_bytes = sizeof(double) * (size_t)(n - 1) * p, out_bytes = sizeof(double) * (size_t)n * p;
-    void* d_in = nullptr;
-    if (vstab_stage_params(ctx, deltas, in_bytes, &d_in)) return 1;
-    if (ctx->d_fit.reserve(2 * out_bytes + 512)) return 1;
-    if (ctx->h_fit.reserve(2 * out_bytes)) return 1;
-    double* d_path = static_cast<double*>(ctx->d_fit.ptr);
-    double* d_target = d_path + (size_t)n * p;
-    const size_t lds = out_bytes;
-    if (lds <= TRAJ_LDS_MAX) {
-        if (lds > 64 * 1024)
-            VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trajectory_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(trajectory_lds_kernel, dim3(1), dim3(TRAJ_T), lds, ctx->stream, static_cast<const double*>(d_in), d_path, d_target, n,
-                           p, window, do_smooth, strength, camera_lock);
-    } else {
-        hipLaunchKernelGGL(trajectory_kernel, dim3(1), dim3(256), 0, ctx->stream, static_cast<const double*>(d_in), d_path, d_target, n, p,
-                           window, do_smooth, strength, camera_lock);
+    const int window = smoothing_window(smooth, fps);
+    // the operation order of plan_kernel: sequential prefix sum per parameter; window sum in tap order, each tap scaled
+    for (int c = 0; c < p; c++) {
+        double acc = 0.0;
+        path[c] = 0.0;
+        for (int i = 1; i < n; i++) {
+            acc = acc + deltas[(size_t)(i - 1) * p + c];
+            path[(size_t)i * p + c] = acc;
+        }
     }
-    VSTAB_HIP(hipGetLastError());
-    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_path, 2 * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(path, ctx->h_fit.ptr, out_bytes);
-    memcpy(target, static_cast<char*>(ctx->h_fit.ptr) + out_bytes, out_bytes);
+    const int pad = window / 2;
+    const double kv = 1.0 / (double)window;
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < p; c++) {
+            const double cur = path[(size_t)i * p + c];
+            double sm = cur;
+            if (do_smooth) {
+                double acc = 0.0;
+                for (int k = 0; k < window; k++) {
+                    int s = i + k - pad;
+                    s = s < 0 ? 0 : (s > n - 1 ? n - 1 : s);
+                    acc += path[(size_t)s * p + c] * kv;
+                }
+                sm = acc;
+            }
+            target[(size_t)i * p + c] = camera_lock ? 0.0 : cur + strength * (sm - cur);
+        }
     return 0;
+}
+
+extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
+                                      const double* up, const double* down, double smooth, double fps, double strength,
+                                      int camera_lock, int width, int height)
+{
+    VSTAB_REQUIRE(ctx != nullptr && d_records != nullptr, "vstab_flow_plan_device: NULL argument");
+    VSTAB_REQUIRE(pairs >= 1, "vstab_flow_plan_device: needs at least one transition");
+    VSTAB_REQUIRE(requested_mode == VSTAB_MODE_TRANSLATION || requested_mode == VSTAB_MODE_SIMILARITY,
+                  "vstab_flow_plan_device: only translation / similarity plans are formed on the device (mode %d)", requested_mode);
+    VSTAB_REQUIRE((up == nullptr) == (down == nullptr), "vstab_flow_plan_device: up and down come together");
+    VSTAB_REQUIRE(width > 0 && height > 0, "vstab_flow_plan_device: non-positive frame size");
+    const int p = requested_mode == VSTAB_MODE_SIMILARITY ? 4 : 2, frames = pairs + 1;
+    const size_t lds = sizeof(double) * ((size_t)frames * p + 4 * (PLAN_T / 64)) + (((size_t)pairs + 15) & ~size_t(15));
+    VSTAB_REQUIRE(lds <= PLAN_LDS_MAX, "vstab_flow_plan_device: a clip of %d frames does not fit the plan kernel's LDS", frames);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const PlanLayout L = plan_layout(frames, p);
+    if (ctx->d_plan.reserve(L.total)) return 1;
+    ctx->h_plan.pinned_host = true;
+    if (ctx->h_plan.reserve(L.xf)) return 1;   // everything but the warp table comes back
+    if (!ctx->ev_plan_done) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_plan_done, hipEventDisableTiming));
+    char* base = static_cast<char*>(ctx->d_plan.ptr);
+    PlanArgs a{};
+    a.rec = d_records; a.pairs = pairs; a.mode = requested_mode;
+    a.rescale = up != nullptr;
+    for (int i = 0; i < 3; i++) { a.up[i] = up ? up[i] : 1.0; a.down[i] = down ? down[i] : 1.0; }
+    smooth = smooth < 0.0 ? 0.0 : (smooth > 1.0 ? 1.0 : smooth);
+    a.strength = strength < 0.0 ? 0.0 : (strength > 1.0 ? 1.0 : strength);
+    a.do_smooth = !(smooth <= 0.0 || frames <= 2);
+    a.window = smoothing_window(smooth, fps);
+    a.camera_lock = camera_lock; a.width = (double)width; a.height = (double)height;
+    a.final32 = reinterpret_cast<float*>(base + L.final32);
+    a.xf = reinterpret_cast<WarpXform*>(base + L.xf);
+    a.path = reinterpret_cast<double*>(base + L.path);
+    a.target = reinterpret_cast<double*>(base + L.target);
+    a.region = reinterpret_cast<double*>(base + L.region);
+    a.perturb = -1;
+    if (const char* e = getenv("VSTAB_DEBUG_PLAN_PERTURB")) a.perturb = atoi(e);
+    if (lds > 64 * 1024)
+        VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_T), lds, ctx->stream, a);
+    VSTAB_HIP(hipGetLastError());
+    // the verification copy is queued BEFORE the warp that follows on this stream, so the host has it while the warp runs
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_plan.ptr, base, L.xf, hipMemcpyDeviceToHost, ctx->stream));
+    VSTAB_HIP(hipEventRecord(ctx->ev_plan_done, ctx->stream));
+    ctx->plan_frames = frames; ctx->plan_params = p;
+    return 0;
+}
+
+extern "C" int vstab_flow_plan_result(vstab_ctx* ctx, int frames, float* final32, double* path, double* target, double* region)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_flow_plan_result: ctx is NULL");
+    VSTAB_REQUIRE(ctx->plan_frames > 0 && frames == ctx->plan_frames, "vstab_flow_plan_result: no device plan of %d frames is pending", frames);
+    VSTAB_HIP(hipEventSynchronize(ctx->ev_plan_done));
+    const PlanLayout L = plan_layout(frames, ctx->plan_params);
+    const char* base = static_cast<const char*>(ctx->h_plan.ptr);
+    if (final32) memcpy(final32, base + L.final32, sizeof(float) * 9 * (size_t)frames);
+    if (path) memcpy(path, base + L.path, sizeof(double) * (size_t)frames * ctx->plan_params);
+    if (target) memcpy(target, base + L.target, sizeof(double) * (size_t)frames * ctx->plan_params);
+    if (region) memcpy(region, base + L.region, sizeof(double) * 4);
+    return 0;
+}
+
+// the warp table of frames [first, first + n) of the last device plan (vstab_warp.hip)
+const WarpXform* vstab_plan_xforms(vstab_ctx* ctx, int first, int n)
+{
+    if (!ctx || ctx->plan_frames <= 0 || first < 0 || n < 1 || first + n > ctx->plan_frames) return nullptr;
+    const PlanLayout L = plan_layout(ctx->plan_frames, ctx->plan_params);
+    return reinterpret_cast<const WarpXform*>(static_cast<const char*>(ctx->d_plan.ptr) + L.xf) + first;
 }

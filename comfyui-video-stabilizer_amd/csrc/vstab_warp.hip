@@ -20,13 +20,7 @@ namespace {
 constexpr int TILE_PX = 2;        // pixels per thread along x, strided by the tile width (profiles/r01_warp_tile_sweep.md)
 constexpr int MAX_BLUR_SAMPLES = 33;
 
-struct WarpXform {   // per (frame, sample)
-    double m[9];     // inverse (output -> source) matrix, as cv::warpPerspective builds it
-    double wq;       // affine only: m8 ? 32/m8 : 0
-    double wn;       // affine only: m8 ? 1/m8 : 0
-    int affine;      // m6 == 0 && m7 == 0
-    int pad_;
-};
+// WarpXform (per frame / sample transform record): vstab_internal.h
 
 struct WarpArgs {
     const float* src;
@@ -697,17 +691,7 @@ int launch_warp_blur(const WarpArgs& a, int interp, int subpix, bool with_mask, 
     return launch_blur<VSTAB_INTERP_BILINEAR, VSTAB_SUBPIX_Q5>(a, with_mask, st);
 }
 
-void fill_xform(const float* m32, WarpXform* xf)
-{
-    double M[9];
-    for (int i = 0; i < 9; i++) M[i] = (double)m32[i];
-    vstab_invert3x3(M, xf->m);
-    xf->affine = (xf->m[6] == 0.0 && xf->m[7] == 0.0) ? 1 : 0;
-    const double W = xf->m[8];
-    xf->wq = (W != 0.0) ? 32.0 / W : 0.0;
-    xf->wn = (W != 0.0) ? 1.0 / W : 0.0;
-    xf->pad_ = 0;
-}
+void fill_xform(const float* m32, WarpXform* xf) { vstab_fill_xform(m32, xf); }
 
 int check_common(const char* who, vstab_ctx* ctx, const void* src, int n, int sh, int sw, const void* mats,
                  int dh, int dw, int interp, const float* border, int subpix, const void* dst)
@@ -750,6 +734,28 @@ extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src
     WarpArgs a{};
     a.src = src; a.dst = dst; a.mask = mask; a.pad_count = pad_count;
     a.xf = static_cast<const WarpXform*>(d_xf);
+    a.samples = 1; a.nxf_per_frame = 1;
+    fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
+    if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+    KernelTimer timer(ctx, "warp");
+    return launch_warp(a, interp, subpix, mask != nullptr, ctx->stream);
+}
+
+const WarpXform* vstab_plan_xforms(vstab_ctx* ctx, int first, int n);   // vstab_traj.hip
+
+// vstab_warp_batch for frames [first, first + n) of the clip whose plan vstab_flow_plan_device left on the device: the
+// transform table is read where the plan kernel wrote it, nothing crosses the host.
+extern "C" int vstab_warp_batch_planned(vstab_ctx* ctx, const float* src, int first, int n, int src_h, int src_w, int out_h,
+                                        int out_w, int interp, const float* border_rgb, int subpix, float* dst, float* mask,
+                                        uint32_t* pad_count)
+{
+    if (int rc = check_common("vstab_warp_batch_planned", ctx, src, n, src_h, src_w, border_rgb, out_h, out_w, interp, border_rgb, subpix, dst)) return rc;
+    const WarpXform* xf = vstab_plan_xforms(ctx, first, n);
+    VSTAB_REQUIRE(xf != nullptr, "vstab_warp_batch_planned: frames [%d, %d) are outside the pending device plan", first, first + n);
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    WarpArgs a{};
+    a.src = src; a.dst = dst; a.mask = mask; a.pad_count = pad_count;
+    a.xf = xf;
     a.samples = 1; a.nxf_per_frame = 1;
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));

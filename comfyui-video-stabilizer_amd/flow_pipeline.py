@@ -440,6 +440,74 @@ def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
     return complete_meta(prepare_meta(plan), plan, pad_counts)
 
 
+# ---- the plan formed on the device, speculatively (csrc/vstab_traj.hip: plan_kernel) ---------------------------------
+# Between the last model fit and the first warp the reference runs its sequential host logic (flow.py:324-371, 472-521).
+# Formed on the host that is a download of the fits, ~0.15 ms of arithmetic, an upload of the matrices and a launch: ~0.24 ms
+# in which the GPU idles (3 % of a C2 step, more of a rank's step in a multi-GPU run).  For the common configuration --
+# DIS estimator, crop_and_pad, translation / similarity -- the same logic runs as one small fp64 kernel behind the fit
+# kernel and the warp is queued behind it at once.  The host still forms the plan, with the HOST's libm as the reference
+# does (it needs the fits for the meta anyway), while the warp runs, then compares its float32 final matrices with the
+# device's bit for bit: a frame whose matrix differs (the device's atan2 / log / exp / cos / sin may differ from glibc's in
+# the last bit of a double, which survives the float32 cast about once in 1e8 entries) is warped again with the host's.
+# What is returned is therefore always the host plan's result.  VSTAB_DEVICE_PLAN=0 switches the speculation off (A/B).
+LAST_DEVICE_PLAN: Dict[str, Any] = {}   # {"used": bool, "mismatched_frames": int} of the last Flow call (tests, bench)
+_DEVICE_PLAN_MAX_FRAMES = 4096          # plan_kernel keeps the path [frames, 4] fp64 in LDS
+
+
+def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, total_frames: int) -> bool:
+    LAST_DEVICE_PLAN.clear()
+    LAST_DEVICE_PLAN.update({"used": False, "mismatched_frames": 0})
+    return (os.environ.get("VSTAB_DEVICE_PLAN", "1") not in ("0", "false", "False") and estimator == "flow"
+            and framing_mode == "crop_and_pad" and transform_mode in ("translation", "similarity")
+            and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES)
+
+
+def _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb) -> int:
+    """Frames whose device-plan matrix is not the host plan's, bit for bit, are warped again with the host's."""
+    host = np.ascontiguousarray(plan.final_matrices, np.float32)
+    bad = np.nonzero((host.view(np.uint32) != np.ascontiguousarray(final_dev).view(np.uint32)).reshape(len(host), -1).any(axis=1))[0]
+    for i in bad.tolist():
+        d2, m2, c2 = ctx.warp_batch(device_frames[i:i + 1], host[i:i + 1], plan.output_size, interp="bilinear",
+                                    border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
+        dst[i].copy_(d2[0])
+        mask[i].copy_(m2[0])
+        counts[i].copy_(c2[0])
+    return int(bad.size)
+
+
+def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total_frames, framing_mode, transform_mode, camera_lock,
+                                strength, smooth, keep_fov, padding_rgb, fps_effective, fps_requested, pbar, progress_total,
+                                keep_on_device):
+    """F2-F14 with the plan formed on the device (see above).  Returns None when F0 found 0..255 float data: the
+    speculative run used the unscaled frames and is discarded; the caller takes the regular path on the rescaled clip."""
+    size = (context.width, context.height)
+    peaks = [] if context.range_pending else None
+    gray = _gray(ctx, device_frames, working_size, peaks)
+    _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True)
+    pairs = ctx.sample_fit_batch_begin(grid, SAMPLE_STEP, transform_mode)
+    ctx.flow_plan_device(ctx.fit_records_device(), pairs, transform_mode, size, working_size, smooth, fps_effective, strength,
+                         bool(camera_lock))
+    dst, mask, counts = ctx.warp_batch_planned(device_frames, 0, size, border=hm.border_value(padding_rgb), want_mask=True,
+                                               want_count=True)
+    fit_records = ctx.sample_fit_batch_end(pairs)          # waits for the fits only; the plan kernel and the warp run on
+    if peaks and hm.resolve_value_range(context, peaks[0], ctx):
+        return None
+    progress_done = _replay_progress(pbar, 0, total_frames - 1, progress_total)
+    check_interrupt()
+    plan = plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
+                              keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
+    meta = prepare_meta(plan)                               # host JSON work overlaps the warp kernel
+    final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
+    LAST_DEVICE_PLAN.update({"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask,
+                                                                                   counts, padding_rgb)})
+    meta = complete_meta(meta, plan, counts.cpu().numpy())
+    _replay_progress(pbar, progress_done, total_frames, progress_total)
+    check_interrupt()
+    if keep_on_device:
+        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
+    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)
+
+
 def _stabilize_frames(
     context: hm.VideoContext,
     framing_mode: str,
@@ -515,6 +583,14 @@ def _stabilize_frames(
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
     working_size = hm._working_estimation_size(context.width, context.height)
+
+    if device_plan_applies(estimator, framing_mode, transform_mode, total_frames):
+        done = _stabilize_with_device_plan(ctx, context, device_frames, working_size, total_frames, framing_mode, transform_mode,
+                                           camera_lock, strength, smooth, keep_fov, padding_rgb, fps_effective, fps_requested,
+                                           pbar, progress_total, keep_on_device)
+        if done is not None:
+            return done
+        device_frames = context.device_batch(ctx)   # F0 rescaled the clip: everything is redone on the rescaled frames below
 
     # ---- estimation (F2-F5) -------------------------------------------------
     estimate = _ESTIMATORS[estimator]

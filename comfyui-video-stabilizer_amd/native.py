@@ -134,6 +134,16 @@ _SIGNATURES = {
     "vstab_dis_set_clip_start": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_sample_fit_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_sample_fit_batch_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vstab_fit_records_device": (C.c_void_p, [C.c_void_p]),
+    "vstab_sample_fit_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "vstab_flow_plan_device": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
+                  C.c_int, C.c_int]),
+    "vstab_flow_plan_result": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vstab_warp_batch_planned": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_gftt_batch": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p,
                   C.c_void_p]),
@@ -495,6 +505,77 @@ class Context:
             "vstab_sample_fit_batch",
         )
         return table
+
+    def sample_fit_batch_begin(self, grid_flow, step, requested_mode):
+        """Launch the fits of sample_fit_batch without waiting: the records stay on the device (fit_records_device) and
+        their download is queued; sample_fit_batch_end(pairs) collects the host table.  Work queued in between (the
+        device plan, the warp) does not delay that download."""
+        if grid_flow.device != self.device:
+            grid_flow = grid_flow.to(self.device)
+        grid_flow = grid_flow.contiguous()
+        pairs, gh, gw, _ = grid_flow.shape
+        self.use_torch_stream()
+        _check(self.lib.vstab_sample_fit_batch_begin(self.handle, _dev_ptr(grid_flow), pairs, gh, gw, int(step), MODES[requested_mode]),
+               "vstab_sample_fit_batch_begin")
+        self._fit_grid = grid_flow   # keep the input alive until the kernels have run
+        return pairs
+
+    def fit_records_device(self) -> int:
+        """Device address of the records of the last sample_fit_batch_begin ([pairs*3] vstab_fit_record)."""
+        ptr = self.lib.vstab_fit_records_device(self.handle)
+        if not ptr:
+            raise VstabError("fit_records_device: no fit is pending")
+        return int(ptr)
+
+    def sample_fit_batch_end(self, pairs):
+        table = np.zeros((pairs, 3), FIT_DTYPE)
+        _check(self.lib.vstab_sample_fit_batch_end(self.handle, int(pairs), table.ctypes.data), "vstab_sample_fit_batch_end")
+        self._fit_grid = None
+        return table
+
+    # ------------------------------------------------------------------ speculative device plan (F6-F12, crop_and_pad)
+    def flow_plan_device(self, records_ptr, pairs, requested_mode, source_size, working_size, smooth, fps, strength, camera_lock):
+        """Queue plan_kernel behind the fits: records (device address) -> the warp's transform table, on the device."""
+        up = down = None
+        if working_size is not None:
+            sx, sy = working_size[0] / float(source_size[0]), working_size[1] / float(source_size[1])
+            up = np.array([1.0 / sx, 1.0 / sy, 1.0], np.float64)
+            down = np.array([sx, sy, 1.0], np.float64)
+        self.use_torch_stream()
+        _check(self.lib.vstab_flow_plan_device(
+            self.handle, C.c_void_p(int(records_ptr)), int(pairs), MODES[requested_mode],
+            up.ctypes.data if up is not None else None, down.ctypes.data if down is not None else None,
+            float(smooth), float(fps), float(strength), 1 if camera_lock else 0, int(source_size[0]), int(source_size[1])),
+            "vstab_flow_plan_device")
+
+    def flow_plan_result(self, frames, params):
+        """(final float32 matrices [frames,3,3], path, target [frames,params], region [4]) of the pending device plan."""
+        final = np.zeros((frames, 3, 3), np.float32)
+        path = np.zeros((frames, params), np.float64)
+        target = np.zeros((frames, params), np.float64)
+        region = np.zeros(4, np.float64)
+        _check(self.lib.vstab_flow_plan_result(self.handle, int(frames), final.ctypes.data, path.ctypes.data, target.ctypes.data,
+                                               region.ctypes.data), "vstab_flow_plan_result")
+        return final, path, target, region
+
+    def warp_batch_planned(self, frames, first, out_size, border=(0.0, 0.0, 0.0), subpix=None, want_mask=True, want_count=False):
+        """warp_batch (bilinear) for frames [first, first + n) of the clip whose plan is pending on the device."""
+        torch = self.torch
+        src = self._as_device_frames(frames)
+        n, sh, sw, ch = src.shape
+        if ch != 3:
+            raise VstabError(f"warp_batch_planned expects 3-channel frames, got {ch}")
+        out_w, out_h = int(out_size[0]), int(out_size[1])
+        b = np.ascontiguousarray(border, dtype=np.float32).reshape(3)
+        dst = torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=self.device)
+        mask = torch.empty((n, out_h, out_w), dtype=torch.float32, device=self.device) if want_mask else None
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device) if (want_count and want_mask) else None
+        self.use_torch_stream()
+        _check(self.lib.vstab_warp_batch_planned(
+            self.handle, _dev_ptr(src), int(first), n, sh, sw, out_h, out_w, INTERP["bilinear"], b.ctypes.data,
+            SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst), _dev_ptr(mask) if mask is not None else None,
+            _dev_ptr(counts) if counts is not None else None), "vstab_warp_batch_planned")
+        return dst, mask, counts
 
     # ------------------------------------------------------------------ Classic estimator (sparse features + LK)
     def gftt_batch(self, gray, max_corners=400, quality=0.01, min_distance=7.0, block_size=21):

@@ -193,6 +193,14 @@ typedef struct vstab_fit_record {
 } vstab_fit_record;
 int vstab_sample_fit_batch(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw,
                            int step, int requested_mode, vstab_fit_record* results);
+/* The same in two halves, so that work can be queued on the stream between the launch and the host's wait:
+ * _begin launches the fits and queues the download of the records behind them; vstab_fit_records_device is the
+ * device copy of those records ([pairs * 3], valid until the next fit call of this context); _end waits for the
+ * download only (not for anything queued after _begin) and hands out the host records. */
+int vstab_sample_fit_batch_begin(vstab_ctx* ctx, const float* grid_flow, int pairs, int gh, int gw,
+                                 int step, int requested_mode);
+const vstab_fit_record* vstab_fit_records_device(vstab_ctx* ctx);
+int vstab_sample_fit_batch_end(vstab_ctx* ctx, int pairs, vstab_fit_record* results);
 
 /* ---- N1 (crop framing): coverage analysis for the keep_fov crop solver ---------
  * Replaces the per-frame cv2 calls of nodes/stabilizer_utils.py:611-643
@@ -266,10 +274,35 @@ int vstab_phase_correlate_batch(vstab_ctx* ctx, const uint8_t* gray, int n, int 
  * Replaces nodes/video_stabilizer_flow.py:356-371 and
  * nodes/stabilizer_utils.py:361-383 (_smooth_path: moving average, edge padded,
  * window from fps).  deltas host [n-1,p]; path/target host [n,p].
+ * Host arithmetic since round 4 (a few thousand doubles; ctx is not used): the same operation order as the
+ * device plan below, so the two agree bit for bit on equal deltas.
  */
 int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double smooth,
                      double fps, double strength, int camera_lock, double* path,
                      double* target);
+
+/* ---- F6-F12 on the device, speculatively: fit records -> the warp's transform table, no host round trip ----
+ * Replaces the stretch of nodes/video_stabilizer_flow.py:324-371 and :472-521 between the last model fit and the first
+ * warp for framing_mode "crop_and_pad" with a translation / similarity model: sticky active_mode walk, rescale to full
+ * resolution, parameter deltas of the requested model, path / _smooth_path / strength blend, _params_to_matrix,
+ * _compute_bounding_boxes, the common region, the recentring shift and final = T @ M (float32), inverted as
+ * cv2.warpPerspective inverts it.  One kernel on the context's stream.
+ *   d_records  dev [pairs*3] (vstab_fit_records_device, or a gathered table of the whole clip)
+ *   up, down   as for vstab_transitions_to_params (NULL: estimated at full size)
+ * The plan stays on the device for vstab_warp_batch_planned; its float32 final matrices, path, target and the common
+ * region (x0, y0, x1, y1) are downloaded behind the kernel and handed out by vstab_flow_plan_result (waits for that
+ * download only).  The device forms atan2 / log / exp / cos / sin with its own fp64 library, the reference with the host's
+ * libm: the caller computes the plan on the host as well (vstab_transitions_to_params ... vstab_bounding_boxes), compares
+ * the final matrices bit for bit and warps a frame again where they differ -- see flow_pipeline.py. */
+int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
+                           const double* up, const double* down, double smooth, double fps, double strength,
+                           int camera_lock, int width, int height);
+int vstab_flow_plan_result(vstab_ctx* ctx, int frames, float* final32, double* path, double* target, double* region);
+/* vstab_warp_batch for frames [first, first + n) of the clip planned by the last vstab_flow_plan_device of this context
+ * (src: those n frames). */
+int vstab_warp_batch_planned(vstab_ctx* ctx, const float* src, int first, int n, int src_h, int src_w, int out_h,
+                             int out_w, int interp, const float* border_rgb, int subpix, float* dst, float* mask,
+                             uint32_t* pad_count);
 
 /* ---- F6 / F9 host helper: element-wise libm over fp64 arrays (host pointers, no GPU involved) ----
  * nodes/stabilizer_utils.py:300-358 (_matrix_to_params / _params_to_matrix) call math.sqrt/atan2/log and

@@ -1,0 +1,191 @@
+"""The plan formed on the device (csrc/vstab_traj.hip: plan_kernel) against the host plan (the reference's arithmetic with
+the host's libm), and the speculation built on it (flow_pipeline._stabilize_with_device_plan): the Flow node returns the
+host plan's result bit for bit whether the device plan is used or not, also when the device plan is (made) wrong."""
+
+import numpy as np
+import pytest
+
+import bench
+from tests.util import shake_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(ctx, n, w, h, kind, amp=1.0, seed=3):
+    cam = shake_path(n, w, h, kind, seed=seed, amp=amp)
+    return bench.synth_clip(n, 0, h, w, ctx.device, mats=cam)
+
+
+def _fits(ctx, frames, mode):
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    n, h, w, _ = frames.shape
+    work = hm._working_estimation_size(w, h)
+    gray = ctx.gray_downscale(frames, work)
+    _, grid = ctx.dis_flow_batch(gray, sample_step=fp.SAMPLE_STEP, want_full=False, want_grid=True)
+    pairs = ctx.sample_fit_batch_begin(grid, fp.SAMPLE_STEP, mode)
+    return pairs, work
+
+
+@pytest.mark.parametrize("mode,size,camera_lock,smooth,strength,fps", [
+    ("similarity", (1920, 1080), False, 0.5, 0.7, 16.0),      # C2's configuration: estimated at 960x540, rescaled
+    ("similarity", (960, 540), False, 1.0, 1.0, 30.0),        # estimated at full size (no rescale), widest window
+    ("similarity", (640, 360), True, 0.5, 0.7, 16.0),         # camera_lock: target path 0
+    ("translation", (960, 540), False, 0.0, 0.4, 16.0),       # smooth 0: the path is its own target
+    ("translation", (1280, 720), False, 0.5, 0.7, 24.0),
+])
+def test_device_plan_equals_host_plan(ctx, pkg, mode, size, camera_lock, smooth, strength, fps):
+    from vstab_amd import flow_pipeline as fp
+
+    w, h = size
+    n = 24
+    frames = _clip(ctx, n, w, h, "similarity" if mode == "similarity" else "translation", amp=1.5)
+    pairs, work = _fits(ctx, frames, mode)
+    ctx.flow_plan_device(ctx.fit_records_device(), pairs, mode, size, work, smooth, fps, strength, camera_lock)
+    table = ctx.sample_fit_batch_end(pairs)
+    final_dev, path_dev, target_dev, region = ctx.flow_plan_result(n, 4 if mode == "similarity" else 2)
+    plan = fp.plan_stabilization(ctx, table, size, n, "crop_and_pad", mode, camera_lock, strength, smooth, 0.6, (127, 127, 127),
+                                 fps, fps)
+    em = plan.estimated_motion
+    # translation parameters involve no libm at all: everything is bit-equal; similarity: the path may differ in the
+    # last unit of a double (device atan2 / log vs glibc), the float32 matrices must still agree
+    if mode == "translation":
+        assert np.array_equal(path_dev, em["path"]) and np.array_equal(target_dev, em["target_path"])
+    else:
+        assert np.allclose(path_dev, em["path"], rtol=0, atol=4e-15 * max(1.0, np.abs(em["path"]).max()))
+        assert np.allclose(target_dev, em["target_path"], rtol=0, atol=4e-15 * max(1.0, np.abs(em["path"]).max()))
+    assert np.array_equal(final_dev.view(np.uint32), plan.final_matrices.view(np.uint32))
+    fm = plan.framing_meta
+    x0, y0 = fm["safe_region_origin"]
+    assert region[0] == x0 and region[1] == y0
+
+
+def test_host_trajectory_equals_the_plan_kernels(ctx, pkg):
+    """vstab_trajectory (host since round 4) and plan_kernel share one operation order: on deltas that involve no libm
+    (translation) the device path / target and the host's are the same bits."""
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import native
+
+    frames = _clip(ctx, 40, 960, 540, "translation", amp=2.0)
+    pairs, work = _fits(ctx, frames, "translation")
+    ctx.flow_plan_device(ctx.fit_records_device(), pairs, "translation", (960, 540), work, 0.5, 16.0, 0.7, False)
+    table = ctx.sample_fit_batch_end(pairs)
+    _, path_dev, target_dev, _ = ctx.flow_plan_result(40, 2)
+    mats = fp.select_transitions(table, "translation")[0]
+    _, deltas = native.transitions_to_params(mats, "translation", (960, 540), work)
+    path, target = ctx.trajectory(deltas, 0.5, 16.0, 0.7, False)
+    assert np.array_equal(path, path_dev) and np.array_equal(target, target_dev)
+
+
+def _run(ctx, frames, mode, monkeypatch, device_plan, perturb=None):
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    monkeypatch.setenv("VSTAB_DEVICE_PLAN", "1" if device_plan else "0")
+    if perturb is None:
+        monkeypatch.delenv("VSTAB_DEBUG_PLAN_PERTURB", raising=False)
+    else:
+        monkeypatch.setenv("VSTAB_DEBUG_PLAN_PERTURB", str(perturb))
+    res = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", mode, False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
+                               ctx=ctx, keep_on_device=True)
+    return res, dict(fp.LAST_DEVICE_PLAN)
+
+
+@pytest.mark.parametrize("mode", ["similarity", "translation"])
+def test_flow_node_is_the_same_with_and_without_the_device_plan(ctx, pkg, monkeypatch, mode):
+    frames = _clip(ctx, 16, 1280, 720, "similarity", amp=1.5)
+    a, info_a = _run(ctx, frames, mode, monkeypatch, device_plan=False)
+    b, info_b = _run(ctx, frames, mode, monkeypatch, device_plan=True)
+    assert info_a == {"used": False, "mismatched_frames": 0} and info_b == {"used": True, "mismatched_frames": 0}
+    assert a.meta == b.meta
+    assert bool((a.frames == b.frames).all()) and bool((a.masks == b.masks).all())
+
+
+def test_a_wrong_device_plan_is_caught_and_the_frame_warped_again(ctx, pkg, monkeypatch):
+    frames = _clip(ctx, 12, 960, 540, "similarity", amp=1.5)
+    want, _ = _run(ctx, frames, "similarity", monkeypatch, device_plan=False)
+    got, info = _run(ctx, frames, "similarity", monkeypatch, device_plan=True, perturb=5)
+    assert info == {"used": True, "mismatched_frames": 1}
+    assert want.meta == got.meta
+    assert bool((want.frames == got.frames).all()) and bool((want.masks == got.masks).all())
+
+
+def test_value_range_rescale_discards_the_speculative_run(ctx, pkg, monkeypatch):
+    """F0: 0..255 float frames are found by the sniff that rides on the gray pass; the speculative warp used the unscaled
+    frames and must not survive."""
+    import torch
+
+    frames = _clip(ctx, 6, 640, 360, "similarity") * 255.0
+    a, info_a = _run(ctx, frames.clone(), "similarity", monkeypatch, device_plan=False)
+    b, info_b = _run(ctx, frames.clone(), "similarity", monkeypatch, device_plan=True)
+    assert info_b["used"] is False
+    assert a.meta == b.meta and bool((a.frames == b.frames).all())
+    assert float(b.frames.max()) <= 1.0 + 1e-6 and torch.isfinite(b.frames).all()
+
+
+def test_plan_kernel_refuses_what_it_does_not_cover(ctx, pkg):
+    from vstab_amd import native
+
+    frames = _clip(ctx, 4, 640, 360, "similarity")
+    pairs, work = _fits(ctx, frames, "perspective")
+    with pytest.raises(native.VstabError, match="translation / similarity"):
+        ctx.flow_plan_device(ctx.fit_records_device(), pairs, "perspective", (640, 360), work, 0.5, 16.0, 0.7, False)
+    ctx.sample_fit_batch_end(pairs)
+    with pytest.raises(native.VstabError, match="no fit"):
+        ctx.sample_fit_batch_end(pairs)
+
+
+@pytest.mark.parametrize("mode", ["similarity", "translation"])
+def test_sticky_mode_on_the_device_equals_the_host_walk(ctx, pkg, mode):
+    """The closed form of the sticky active_mode rule in plan_kernel (first unusable similarity fit -> translation from
+    there on; no candidate -> identity) against flow_pipeline.select_transitions' pair-by-pair walk, on tables with
+    rejected similarity fits, pairs without any candidate, and a rejected LAST / FIRST pair."""
+    import torch
+
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import native
+
+    rng = np.random.default_rng(11)
+    pairs = 37
+    for case in range(6):
+        table = np.zeros((pairs, 3), native.FIT_DTYPE)
+        for i in range(pairs):
+            for m in (0, 1):
+                mat = np.eye(3, dtype=np.float32)
+                mat[0, 2], mat[1, 2] = rng.uniform(-3, 3, 2)
+                if m == 1:
+                    c, s_ = np.cos(rng.uniform(-0.01, 0.01)), np.sin(rng.uniform(-0.01, 0.01))
+                    mat[0, 0] = mat[1, 1] = 1.002 * c
+                    mat[0, 1], mat[1, 0] = -1.002 * s_, 1.002 * s_
+                table[i, m]["matrix"] = mat.reshape(9)
+                table[i, m]["computed"] = 1 if (m == 0 or mode == "similarity") else 0
+                table[i, m]["accepted"] = table[i, m]["computed"]
+                table[i, m]["confidence"] = 0.9
+        if case == 1:
+            table[20, 1]["accepted"] = 0                                   # similarity rejected mid-clip: translation from there
+        elif case == 2:
+            table[0, 1]["accepted"] = 0                                    # ... at the first pair
+        elif case == 3:
+            table[pairs - 1, 1]["accepted"] = 0                            # ... at the last pair
+        elif case == 4:
+            table[9, 1]["accepted"] = 0
+            table[9, 0]["accepted"] = 0                                    # no candidate at all: identity
+            table[25, 0]["computed"] = 0
+        elif case == 5:
+            table[5, 0]["accepted"] = 0                                    # unusable translation while similarity is still active: ignored
+            table[12, 1]["computed"] = 0
+            table[30, 0]["accepted"] = 0
+        dev = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).to(ctx.device)
+        ctx.flow_plan_device(dev.data_ptr(), pairs, mode, (1920, 1080), (960, 540), 0.5, 16.0, 0.7, False)
+        final_dev = ctx.flow_plan_result(pairs + 1, 4 if mode == "similarity" else 2)[0]
+        plan = fp.plan_stabilization(ctx, table, (1920, 1080), pairs + 1, "crop_and_pad", mode, False, 0.7, 0.5, 0.6,
+                                     (127, 127, 127), 16.0, 16.0)
+        # A wrong choice anywhere would move entries by ~1e-3.  Bit equality is NOT asserted here: after a fallback to
+        # translation the rotation path is exactly constant, its smoothed value differs from it by a rounding error whose
+        # presence depends on the last bit of the path (device atan2 vs glibc), and a correction of 0 vs 9e-19 rad is
+        # visible in float32 -- the one situation in which the verification of the speculative plan does find differing
+        # matrices and warps those frames again (test_a_wrong_device_plan_is_caught_and_the_frame_warped_again).
+        assert np.abs(final_dev.astype(np.float64) - plan.final_matrices).max() < 1e-12, (mode, case)
+        if case < 4:
+            assert np.array_equal(final_dev.view(np.uint32), plan.final_matrices.view(np.uint32)), (mode, case)
