@@ -482,6 +482,14 @@ extern "C" const vstab_fit_record* vstab_fit_records_device(vstab_ctx* ctx)
     return (ctx && ctx->fit_pairs_pending > 0) ? static_cast<const vstab_fit_record*>(ctx->d_fit.ptr) : nullptr;
 }
 
+extern "C" int vstab_fit_records_copy(vstab_ctx* ctx, void* dst_dev, int pairs)
+{
+    VSTAB_REQUIRE(ctx != nullptr && dst_dev != nullptr, "vstab_fit_records_copy: NULL argument");
+    VSTAB_REQUIRE(ctx->fit_pairs_pending > 0 && pairs == ctx->fit_pairs_pending, "vstab_fit_records_copy: no fit of %d pairs is pending", pairs);
+    VSTAB_HIP(hipMemcpyAsync(dst_dev, ctx->d_fit.ptr, sizeof(vstab_fit_record) * (size_t)pairs * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
 extern "C" int vstab_sample_fit_batch_end(vstab_ctx* ctx, int pairs, vstab_fit_record* results)
 {
     VSTAB_REQUIRE(ctx != nullptr && results != nullptr, "vstab_sample_fit_batch_end: NULL argument");

@@ -28,8 +28,13 @@ namespace {
 constexpr int PLAN_T = 1024;
 constexpr size_t PLAN_LDS_MAX = 144 * 1024;
 
+constexpr int PLAN_MAX_SEG = 64;
+
 struct PlanArgs {
-    const vstab_fit_record* rec;   // [pairs][3], indexed [pair][mode]
+    const vstab_fit_record* rec;   // [pairs][3], indexed [pair][mode]; or a gathered table, see seg_*
+    int segments;                  // 0: contiguous.  > 0: the all-gather's receive buffer as it is -- one block of seg_rows
+    int seg_rows;                  //    records rows per rank, of which the first seg_start[r + 1] - seg_start[r] are valid
+    int seg_start[PLAN_MAX_SEG + 1];
     int pairs, mode;               // requested model: VSTAB_MODE_TRANSLATION | VSTAB_MODE_SIMILARITY
     int rescale;                   // 1: F = f32(fl(up_i * M_ij) * down_j), 0: F = M
     double up[3], down[3];
@@ -42,6 +47,15 @@ struct PlanArgs {
     double* region;                // [4]: x0, y0, x1, y1 of the common region (tests)
     int perturb;                   // tests (VSTAB_DEBUG_PLAN_PERTURB=frame): that frame's matrix is made wrong by one ulp
 };
+
+// the records of pair i (three, indexed by mode)
+__device__ __forceinline__ const vstab_fit_record* pair_records(const PlanArgs& a, int i)
+{
+    if (a.segments <= 0) return a.rec + (size_t)i * 3;
+    int s = 0;
+    while (s + 1 < a.segments && i >= a.seg_start[s + 1]) s++;
+    return a.rec + ((size_t)s * a.seg_rows + (size_t)(i - a.seg_start[s])) * 3;
+}
 
 __device__ __forceinline__ double np_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
 __device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     if (a.mode == VSTAB_MODE_SIMILARITY) {
         int mine = a.pairs;
         for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
-            const vstab_fit_record& r = a.rec[(size_t)i * 3 + VSTAB_MODE_SIMILARITY];
+            const vstab_fit_record& r = pair_records(a, i)[VSTAB_MODE_SIMILARITY];
             if (!(r.computed != 0 && r.accepted != 0)) { mine = i; break; }   // this thread's pairs ascend
         }
         if (mine < a.pairs) atomicMin(&s_first, mine);
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
         int pick = VSTAB_MODE_SIMILARITY;
         if (i >= s_first) {
-            const vstab_fit_record& r = a.rec[(size_t)i * 3 + VSTAB_MODE_TRANSLATION];
+            const vstab_fit_record& r = pair_records(a, i)[VSTAB_MODE_TRANSLATION];
             pick = (r.computed != 0 && r.accepted != 0) ? VSTAB_MODE_TRANSLATION : -1;
         }
         s_mode[i] = (signed char)pick;
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
         float M[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
         const int pick = s_mode[i];
         if (pick >= 0) {
-            const float* src = a.rec[(size_t)i * 3 + pick].matrix;
+            const float* src = pair_records(a, i)[pick].matrix;
             for (int k = 0; k < 9; k++) M[k] = src[k];
         }
         float F[9];
@@ -291,7 +305,7 @@ extern "C" int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int
 
 extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
                                       const double* up, const double* down, double smooth, double fps, double strength,
-                                      int camera_lock, int width, int height)
+                                      int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows)
 {
     VSTAB_REQUIRE(ctx != nullptr && d_records != nullptr, "vstab_flow_plan_device: NULL argument");
     VSTAB_REQUIRE(pairs >= 1, "vstab_flow_plan_device: needs at least one transition");
@@ -311,6 +325,19 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     char* base = static_cast<char*>(ctx->d_plan.ptr);
     PlanArgs a{};
     a.rec = d_records; a.pairs = pairs; a.mode = requested_mode;
+    VSTAB_REQUIRE(segments >= 0 && segments <= PLAN_MAX_SEG, "vstab_flow_plan_device: %d segments (at most %d)", segments, PLAN_MAX_SEG);
+    a.segments = segments; a.seg_rows = seg_rows;
+    if (segments > 0) {
+        VSTAB_REQUIRE(seg_pairs != nullptr && seg_rows >= 1, "vstab_flow_plan_device: a segmented table needs seg_pairs and seg_rows");
+        int acc = 0;
+        for (int r = 0; r < segments; r++) {
+            VSTAB_REQUIRE(seg_pairs[r] >= 0 && seg_pairs[r] <= seg_rows, "vstab_flow_plan_device: segment %d holds %d pairs of %d rows", r, seg_pairs[r], seg_rows);
+            a.seg_start[r] = acc;
+            acc += seg_pairs[r];
+        }
+        a.seg_start[segments] = acc;
+        VSTAB_REQUIRE(acc == pairs, "vstab_flow_plan_device: the segments hold %d pairs, the clip has %d", acc, pairs);
+    }
     a.rescale = up != nullptr;
     for (int i = 0; i < 3; i++) { a.up[i] = up ? up[i] : 1.0; a.down[i] = down ? down[i] : 1.0; }
     smooth = smooth < 0.0 ? 0.0 : (smooth > 1.0 ? 1.0 : smooth);

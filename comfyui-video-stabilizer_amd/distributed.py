@@ -30,6 +30,7 @@ import numpy as np
 import time
 
 from . import host_math as hm
+from . import flow_pipeline as _fp
 from .flow_pipeline import (_ESTIMATORS, _attach_motion_meta, complete_meta, resolve_flow_backend, plan_stabilization,
                             prepare_meta)
 
@@ -175,6 +176,12 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     estimator = resolve_flow_backend(estimator)
     estimate = _ESTIMATORS[estimator]
     t0 = time.perf_counter()
+    # A function of the call's arguments and the backend only, hence the same on every rank: the ranks issue the same two
+    # collectives either way (the fit records' all-gather has one shape in both forms).
+    if dev is not None and _fp.device_plan_applies(estimator, framing_mode, transform_mode, total_frames):
+        return _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_local, halo, size, working_size,
+                                              framing_mode, transform_mode, camera_lock, strength, smooth, keep_fov, padding_rgb,
+                                              fps_effective, fps_requested, group, stats, want_meta, check_value_range, t0)
     if local_frames.shape[0] >= 2:
         peaks = [] if check_value_range else None
         local_records = estimate(ctx, local_frames, working_size, transform_mode, clip_start=(rank == 0), peaks_out=peaks)
@@ -211,6 +218,90 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
         counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
     fetch_counts = _start_gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=dev is not None)
     t0 = _lap(stats, "warp_launch", t0)
+    meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel and the collective
+    t0 = _lap(stats, "meta", t0)
+    all_counts = fetch_counts()
+    if want_meta:
+        meta = complete_meta(meta, plan, all_counts)
+    _lap(stats, "gather_counts", t0)
+    return dst, mask, meta
+
+
+def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_local, halo, size, working_size, framing_mode,
+                                   transform_mode, camera_lock, strength, smooth, keep_fov, padding_rgb, fps_effective,
+                                   fps_requested, group, stats, want_meta, check_value_range, t0):
+    """stabilize_sharded with the plan formed on the device (flow_pipeline: "the plan formed on the device, speculatively"),
+    RCCL only: a rank's fit records go from the fit kernel into the all-gather's send buffer on the device, the gathered
+    table feeds plan_kernel where RCCL leaves it, and the rank's warp is queued behind that -- the rank's GPU never waits
+    for its host.  Every rank then downloads the gathered table, forms the replicated host plan (exact, the reference's
+    arithmetic) WHILE its warp runs, and checks its own frames' matrices against the device plan's."""
+    import torch.distributed as dist
+
+    from . import native
+
+    torch = ctx.torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rec_bytes = 3 * native.FIT_DTYPE.itemsize
+    per_rank = transition_counts(total_frames, world)
+    rows = max(max(per_rank), 1)
+    send = torch.zeros((rows, rec_bytes), dtype=torch.uint8, device=ctx.device)
+    pairs_local = 0
+    if local_frames.shape[0] >= 2:
+        def launch(frames):
+            peaks_ = [] if check_value_range else None
+            gray = _fp._gray(ctx, frames, working_size, peaks_)
+            _, grid = ctx.dis_flow_batch(gray, sample_step=_fp.SAMPLE_STEP, want_full=False, want_grid=True, clip_start=(rank == 0))
+            return ctx.sample_fit_batch_begin(grid, _fp.SAMPLE_STEP, transform_mode), peaks_
+
+        pairs_local, peaks = launch(local_frames)
+        if peaks:
+            rescaled, _ = hm.apply_value_range(local_frames, peaks[0], ctx)
+            if rescaled is not local_frames:   # 0..255 float frames on this rank: estimate again on the rescaled ones
+                ctx.sample_fit_batch_end(pairs_local)
+                local_frames = rescaled
+                check_value_range = False
+                pairs_local, _ = launch(local_frames)
+        ctx.fit_records_copy(send, pairs_local)
+    elif check_value_range and local_frames.shape[0] == 1:
+        local_frames, _ = hm.apply_value_range(local_frames, ctx.frame_range(local_frames), ctx)
+    if pairs_local != per_rank[rank]:
+        raise ValueError(f"rank {rank} produced {pairs_local} transitions, expected {per_rank[rank]}")
+    t0 = _lap(stats, "estimate", t0)
+    flat = torch.empty((world, rows, rec_bytes), dtype=torch.uint8, device=ctx.device)
+    dist.all_gather_into_tensor(flat, send, group=group)
+    # the host's copy of the gathered table is queued HERE, ahead of the plan kernel and the warp in stream order, into
+    # page-locked memory with an event of its own: a plain .cpu() after the launches would wait for the warp to finish
+    host_t = torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True)
+    host_t.copy_(flat, non_blocking=True)
+    gathered = torch.cuda.Event()
+    gathered.record()
+    ctx.flow_plan_device(flat.data_ptr(), total_frames - 1, transform_mode, size, working_size, smooth, fps_effective, strength,
+                         bool(camera_lock), seg_pairs=per_rank, seg_rows=rows)
+    own = local_frames[halo:]
+    if n_local > 0:
+        dst, mask, counts = ctx.warp_batch_planned(own, start, size, border=hm.border_value(padding_rgb), want_mask=True,
+                                                   want_count=True)
+    else:   # nothing to warp here, but this rank still takes part in the second collective below
+        dst = torch.empty((0, size[1], size[0], 3), dtype=torch.float32, device=own.device)
+        mask = torch.empty((0, size[1], size[0]), dtype=torch.float32, device=own.device)
+        counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
+    t0 = _lap(stats, "warp_launch", t0)
+    if pairs_local:
+        ctx.sample_fit_batch_end(pairs_local)      # this rank's fits are done (and its DIS reported no failure)
+    gathered.synchronize()                         # waits for the all-gather and its download, not for the warp
+    host = host_t.numpy()
+    records = np.ascontiguousarray(np.concatenate([host[r, : per_rank[r]] for r in range(world)], axis=0)).view(native.FIT_DTYPE).reshape(-1, 3)
+    t0 = _lap(stats, "gather_fits", t0)
+    plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
+                              keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
+    t0 = _lap(stats, "plan", t0)
+    final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
+    mismatched = 0
+    if n_local > 0:
+        sub = _fp.FlowPlan(plan.final_matrices[start:start + n_local], plan.output_size, {}, {}, {}, plan.framing_mode, size, fps_effective)
+        mismatched = _fp._rewarp_mismatched(ctx, own, sub, final_dev[start:start + n_local], dst, mask, counts, padding_rgb)
+    _fp.LAST_DEVICE_PLAN.update({"used": True, "mismatched_frames": mismatched})
+    fetch_counts = _start_gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=True)
     meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel and the collective
     t0 = _lap(stats, "meta", t0)
     all_counts = fetch_counts()

@@ -139,7 +139,8 @@ _SIGNATURES = {
     "vstab_sample_fit_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_flow_plan_device": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
-                  C.c_int, C.c_int]),
+                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "vstab_fit_records_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_flow_plan_result": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_warp_batch_planned": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -534,18 +535,27 @@ class Context:
         return table
 
     # ------------------------------------------------------------------ speculative device plan (F6-F12, crop_and_pad)
-    def flow_plan_device(self, records_ptr, pairs, requested_mode, source_size, working_size, smooth, fps, strength, camera_lock):
-        """Queue plan_kernel behind the fits: records (device address) -> the warp's transform table, on the device."""
+    def fit_records_copy(self, dst, pairs):
+        """The pending fit's device records into `dst` (device uint8 tensor of >= pairs * 3 records), stream-ordered."""
+        self.use_torch_stream()
+        _check(self.lib.vstab_fit_records_copy(self.handle, _dev_ptr(dst), int(pairs)), "vstab_fit_records_copy")
+
+    def flow_plan_device(self, records_ptr, pairs, requested_mode, source_size, working_size, smooth, fps, strength, camera_lock,
+                         seg_pairs=None, seg_rows=0):
+        """Queue plan_kernel behind the fits: records (device address) -> the warp's transform table, on the device.
+        seg_pairs / seg_rows: the records are an all-gather's receive buffer (seg_rows pairs per rank, seg_pairs[r] valid)."""
         up = down = None
         if working_size is not None:
             sx, sy = working_size[0] / float(source_size[0]), working_size[1] / float(source_size[1])
             up = np.array([1.0 / sx, 1.0 / sy, 1.0], np.float64)
             down = np.array([sx, sy, 1.0], np.float64)
+        seg = np.ascontiguousarray(seg_pairs, np.int32) if seg_pairs is not None else None
         self.use_torch_stream()
         _check(self.lib.vstab_flow_plan_device(
             self.handle, C.c_void_p(int(records_ptr)), int(pairs), MODES[requested_mode],
             up.ctypes.data if up is not None else None, down.ctypes.data if down is not None else None,
-            float(smooth), float(fps), float(strength), 1 if camera_lock else 0, int(source_size[0]), int(source_size[1])),
+            float(smooth), float(fps), float(strength), 1 if camera_lock else 0, int(source_size[0]), int(source_size[1]),
+            len(seg) if seg is not None else 0, seg.ctypes.data if seg is not None else None, int(seg_rows)),
             "vstab_flow_plan_device")
 
     def flow_plan_result(self, frames, params):

@@ -296,7 +296,13 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
  * the final matrices bit for bit and warps a frame again where they differ -- see flow_pipeline.py. */
 int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
                            const double* up, const double* down, double smooth, double fps, double strength,
-                           int camera_lock, int width, int height);
+                           int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows);
+/* segments = 0: d_records is [pairs*3].  segments = world > 0 (multi-GPU): d_records is the receive buffer of the ranks'
+ * all-gather as RCCL leaves it -- one block of seg_rows pairs per rank, of which the first seg_pairs[r] are valid -- so the
+ * gathered table feeds the plan where it lands (no compaction pass, no host copy before the warp). */
+/* Copies the records of the last vstab_sample_fit_batch_begin (device) to dst (device, >= pairs*3 records), stream-ordered:
+ * how a rank places its records in its all-gather send buffer. */
+int vstab_fit_records_copy(vstab_ctx* ctx, void* dst_dev, int pairs);
 int vstab_flow_plan_result(vstab_ctx* ctx, int frames, float* final32, double* path, double* target, double* region);
 /* vstab_warp_batch for frames [first, first + n) of the clip planned by the last vstab_flow_plan_device of this context
  * (src: those n frames). */

@@ -53,6 +53,9 @@ def _worker(rank, world, port, out_dir, estimator, framing="expand", keep_fov=0.
         np.save(Path(out_dir) / f"dst_{rank}.npy", dst.cpu().numpy())
         np.save(Path(out_dir) / f"mask_{rank}.npy", mask.cpu().numpy())
         (Path(out_dir) / f"meta_{rank}.json").write_text(json.dumps(meta))
+        from vstab_amd import flow_pipeline as fp_
+
+        (Path(out_dir) / f"device_plan_{rank}.json").write_text(json.dumps(fp_.LAST_DEVICE_PLAN))
         if backend == "nccl":   # the replay half of BASELINE C5 under the same process group (it issues no collective)
             from vstab_amd import apply_pipeline as ap
 
@@ -90,6 +93,22 @@ def _spawn(world, tmp_path, *extra):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(world, port, str(tmp_path)) + extra, nprocs=world, join=True)
+
+
+def test_sharded_device_plan_under_rccl_equals_single_process(pkg, ctx, tmp_path):
+    """The speculative device plan of the sharded path (distributed._stabilize_sharded_device_plan: fit records device ->
+    all_gather_into_tensor -> plan_kernel on the gathered table -> warp, host plan + verification meanwhile) inside a real
+    "nccl" group (a world of one: RCCL refuses two ranks on one device), crop_and_pad + similarity = the C4 configuration;
+    equal to the single-process node bit for bit, and the speculation was taken with no frame warped twice."""
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    _spawn(1, tmp_path, "flow", "crop_and_pad", 0.6, 9, "nccl")
+    frames = _clip()
+    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+    assert json.loads((tmp_path / "device_plan_0.json").read_text()) == {"used": True, "mismatched_frames": 0}
+    assert np.array_equal(np.load(tmp_path / "dst_0.npy"), ref.frames) and np.array_equal(np.load(tmp_path / "mask_0.npy"), ref.masks[..., 0])
+    assert json.loads((tmp_path / "meta_0.json").read_text()) == json.loads(json.dumps(ref.meta))
 
 
 def test_rccl_branches_run_with_a_world_of_one(pkg, ctx, tmp_path):
