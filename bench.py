@@ -438,9 +438,11 @@ def measure_host_roundtrip(nodes, frames_host, repeats: int = 2) -> dict:
             "note": "CPU tensor in -> Video Stabilizer Flow node -> CPU tensors out, best of %d" % repeats}
 
 
-def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
+def measure_motion_apply(ctx, torch, device, steps: int = 3, check: bool = True) -> dict:
     """Motion Apply rates for BASELINE configs C3 / C5 (per-GPU share), device-resident, HIP-event kernel time and
-    wall time per pass; the motion comes from the reference's shake generator blocks (tests/golden/shake_*.json)."""
+    wall time per pass; the motion comes from the reference's shake generator blocks (tests/golden/shake_*.json).
+    check: one blurred frame of each leg (frame 1) is compared with the CPU oracle's rendering of it from a 2-frame window
+    (part of the cpu_baseline leg: the oracle is the checker; outside every timed region) -> `oracle_spot_check`."""
     from vstab_amd import apply_pipeline as ap
     from vstab_amd import host_math as hm
 
@@ -460,6 +462,25 @@ def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
 
         r = once()
         shape = list(r.frames.shape)
+        spot = None
+        if check:
+            try:
+                from oracle import oracle as vo
+
+                m64 = np.array([e["matrix"] for e in meta["motion_meta"]["per_frame"]], np.float64)
+                if framing == "expand":   # motion_apply.py:288-294: canvas and shift from all the clip's matrices
+                    mins, maxs = hm._compute_bounding_boxes(list(m64), w, h)
+                    shift, size = hm._prepare_expand_transform(mins, maxs)
+                    m64 = np.stack([shift @ m for m in m64])
+                    assert list(size) == [shape[2], shape[1]]
+                ref, ref_mask = vo.warp_blur_clip(frames[1:3].cpu().numpy(), m64[1:3], (shape[2], shape[1]), 0.5, samples, interp=interp,
+                                                  border=hm.border_value((127, 127, 127)))
+                spot = {"frame": 1, "pixels_differing": int(np.count_nonzero(r.frames[1].cpu().numpy() != ref[0])),
+                        "mask_pixels_differing": int(np.count_nonzero(r.masks[1, ..., 0].cpu().numpy() != ref_mask[0])),
+                        "values": int(ref[0].size)}
+                del ref, ref_mask
+            except Exception as exc:
+                spot = {"error": f"{type(exc).__name__}: {exc}"}
         del r
         torch.cuda.synchronize()
         ctx.set_timing(True)
@@ -476,6 +497,8 @@ def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
                     "kernel_ms": round(kernel_ms, 2), "samples_per_s": round(px * samples / (kernel_ms * 1e-3), 0),
                     "hbm_GBs_algorithmic": round(WARP_BYTES_PER_PIXEL * px / (kernel_ms * 1e-3) / 1e9, 1),
                     "bound": "valu (not HBM): S x (f64 coordinates + taps) per output pixel"}
+        if spot is not None:
+            out[key]["oracle_spot_check"] = spot
         del frames
         torch.cuda.empty_cache()
     return out
@@ -483,14 +506,23 @@ def measure_motion_apply(ctx, torch, device, steps: int = 3) -> dict:
 
 C5_FLOW_ARGS = ("expand", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
 C5_APPLY = dict(framing_mode="expand", interpolation="bilinear", motion_blur=0.5, motion_blur_samples=33)
+C3_FLOW_ARGS = ("crop_and_pad", "perspective", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+C3_APPLY = dict(framing_mode="crop_and_pad", interpolation="bicubic", motion_blur=0.5, motion_blur_samples=17)
+CHAINS = {
+    "c5": (C5_FLOW_ARGS, C5_APPLY, "C5", "Flow (DIS) similarity + expand -> Motion Apply expand, bilinear, motion_blur 0.5, Ultra (33 samples)"),
+    "c3": (C3_FLOW_ARGS, C3_APPLY, "C3", "Flow (DIS) perspective + crop_and_pad -> Motion Apply crop_and_pad, bicubic, motion_blur 0.5, High (17 samples)"),
+}
 
 
-def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, warmup) -> dict:
-    """BASELINE configs[4]: Flow (DIS, similarity) with expand framing, then Motion Apply (expand, bilinear, motion_blur
-    0.5, Ultra = 33 samples) on the ORIGINAL frames with the returned meta (call shapes: video_stabilizer_flow.py:734-763,
+def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, warmup, chain: str = "c5") -> dict:
+    """A Flow -> Motion Apply chain as ONE timed step.  chain "c5" = BASELINE configs[4]: Flow (DIS, similarity) with expand
+    framing, then Motion Apply (expand, bilinear, motion_blur 0.5, Ultra = 33 samples); chain "c3" = BASELINE configs[2]:
+    Flow perspective + crop_and_pad, then Motion Apply (crop_and_pad, bicubic, motion_blur 0.5, High = 17 samples) -- on the
+    ORIGINAL frames with the returned meta (call shapes: video_stabilizer_flow.py:734-763,
     video_stabilizer_motion_apply.py:86-129), one `total`-frame clip sharded contiguously over the ranks.  The Flow half
     has the one all-gather of fit records (+ the pad counts); the replay half has no collective (distributed.py).
     Timed like the headline: barrier + synchronize on both sides, MAX over ranks."""
+    C5_FLOW_ARGS, C5_APPLY, tag, what = CHAINS[chain]   # (shadows the module constants: the body below is the same for both)
     from vstab_amd import apply_pipeline as ap
     from vstab_amd import distributed as vd
     from vstab_amd import flow_pipeline as fp
@@ -499,8 +531,25 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
     start, end = vd.shard_range(total, world, rank)
     n_local = end - start
     halo = 1 if (rank > 0 and n_local > 0) else 0
-    frames = synth_clip(n_local + halo, start - halo, h, w, device)
-    torch.cuda.synchronize()
+
+    def agree(ok: bool, what: str) -> None:
+        """All ranks continue, or all ranks give up TOGETHER: a rank that failed alone (out of memory while the others
+        fit, a VstabError) must not leave the others waiting in the chain's collectives -- as an extra on the headline
+        line that would lose the headline too."""
+        if use_dist:
+            flag = torch.tensor([1 if ok else 0], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        if not ok:
+            raise RuntimeError(f"{what} failed on at least one rank; all ranks skip the chain")
+
+    try:
+        frames = synth_clip(n_local + halo, start - halo, h, w, device)
+        torch.cuda.synchronize()
+        alloc_ok = True
+    except Exception:   # typically out of memory for the 4K shard
+        frames, alloc_ok = None, False
+    agree(alloc_ok, "allocating the clip")
     stats: dict = {}
     lap = {"flow": 0.0, "apply": 0.0}
 
@@ -526,7 +575,16 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
+    # the first pass (outputs allocated, LDS attributes set, every code path taken) runs alone, and its verdict is agreed
+    # on before the timed passes: what can fail on one rank only fails here
+    try:
+        out = step()
+        del out
+        first_ok = True
+    except Exception:
+        first_ok = False
+    agree(first_ok, "the first pass of the chain")
+    for _ in range(max(0, warmup - 1)):
         out = step()
         del out
     fence()
@@ -550,8 +608,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
         stage_ms[kind] = round(total_ms / max(launches, 1), 3)
     del frames
     torch.cuda.empty_cache()
-    out = {"workload": f"C5: one {total}-frame {w}x{h} clip, Flow (DIS) similarity + expand -> Motion Apply expand, bilinear, "
-                       "motion_blur 0.5, Ultra (33 samples) on the original frames, device-resident",
+    out = {"workload": f"{tag}: one {total}-frame {w}x{h} clip, {what} on the original frames, device-resident",
            "value": round(total * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "total_frames": total,
            "frames_per_gpu": n_local, "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "scaling": "strong", "out_shape_rank0": shape, "motion_blur_samples": ameta["motion_apply"]["motion_blur_samples"],
@@ -572,9 +629,10 @@ def main() -> int:
     ap_.add_argument("--total-frames", type=int, default=None, help="clip length sharded over all GPUs (strong scaling); default at N>1: C4 = 1024")
     ap_.add_argument("--height", type=int, default=None, help="default 1080 (2160 for --workload c5)")
     ap_.add_argument("--width", type=int, default=None, help="default 1920 (3840 for --workload c5)")
-    ap_.add_argument("--workload", choices=("auto", "c5"), default="auto",
+    ap_.add_argument("--workload", choices=("auto", "c5", "c3"), default="auto",
                      help="auto: C2 at N=1 / C4 at N>1 (the headline metric; at N>1 a C5 object rides on the same line). "
-                          "c5: time BASELINE configs[4] (512 x 4K Flow expand -> Motion Apply blur Ultra) as the line's value")
+                          "c5: time BASELINE configs[4] (512 x 4K Flow expand -> Motion Apply blur Ultra) as the line's value. "
+                          "c3: time BASELINE configs[2] (256 x 1080p Flow perspective -> Motion Apply bicubic, blur 0.5, High)")
     ap_.add_argument("--c5-frames", type=int, default=None, help="clip length of the C5 workload (default: 512 over N > 1 GPUs; 64 = one GPU's share of the 8-GPU config at N = 1)")
     ap_.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (rehearsal)")
     ap_.add_argument("--cpu-frames", type=int, default=256, help="frames of the clip timed on the CPU oracle (0 = skip)")
@@ -610,10 +668,14 @@ def main() -> int:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+
+        # a collective that never completes (a rank that died) becomes an error after ten minutes, not a silent hang
+        limit = datetime.timedelta(minutes=10)
         if args.rehearse_on_one_gpu:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=limit)
         else:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, timeout=limit)
 
     import __graft_entry__ as graft
 
@@ -626,12 +688,18 @@ def main() -> int:
     ctx = native.Context(dev_index)
     ctx.set_timing(True)
 
-    if args.workload == "c5":
-        h, w = args.height or 2160, args.width or 3840
-        total5 = args.c5_frames or args.total_frames or (512 if world > 1 else 64)   # one GPU: the per-GPU share of the 8-GPU config
-        c5 = run_c5(ctx, torch, dist, device, rank, world, use_dist, total5, h, w, args.steps, args.warmup)
+    if args.workload in ("c5", "c3"):
+        if args.workload == "c5":
+            h, w = args.height or 2160, args.width or 3840
+            total5 = args.c5_frames or args.total_frames or (512 if world > 1 else 64)   # one GPU: the per-GPU share of the 8-GPU config
+            metric = "stabilized + motion-blurred frames/sec (4K, Flow expand -> Motion Apply Ultra; BASELINE configs[4])"
+        else:
+            h, w = args.height or 1080, args.width or 1920
+            total5 = args.total_frames or 256
+            metric = "stabilized + motion-blurred frames/sec (1080p, Flow perspective -> Motion Apply bicubic High; BASELINE configs[2])"
+        c5 = run_c5(ctx, torch, dist, device, rank, world, use_dist, total5, h, w, args.steps, args.warmup, chain=args.workload)
         if rank == 0:
-            line = {"metric": "stabilized + motion-blurred frames/sec (4K, Flow expand -> Motion Apply Ultra; BASELINE configs[4])",
+            line = {"metric": metric,
                     "value": c5["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": c5["ms_per_step"], "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic", "config": c5}
@@ -803,7 +871,7 @@ def main() -> int:
                     del host
                     del frames
                     torch.cuda.empty_cache()
-                    line["motion_apply"] = measure_motion_apply(ctx, torch, device)
+                    line["motion_apply"] = measure_motion_apply(ctx, torch, device, check=checks and args.cpu_frames >= 2)
                 except Exception as exc:  # the headline line must survive a failure of the extras
                     line["extras_error"] = f"{type(exc).__name__}: {exc}"
     c5 = None
@@ -815,7 +883,7 @@ def main() -> int:
         try:
             c5 = run_c5(ctx, torch, dist, device, rank, world, True, args.c5_frames or (512 if world > 1 else 64), 2160, 3840,
                         max(2, args.steps // 2), 1)
-        except Exception as exc:   # all ranks fail alike (shape / memory), never one of them inside a collective
+        except Exception as exc:   # run_c5 agrees on allocation and on its first pass across the ranks before it times anything
             c5 = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         if c5 is not None:

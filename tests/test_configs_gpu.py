@@ -176,3 +176,48 @@ def test_c3_at_baseline_frame_count_sampled_frames_match_oracle(api, ctx, oracle
         k = i - lo
         assert np.array_equal(out.frames[i].cpu().numpy(), ref[k]), i
         assert np.array_equal(out.masks[i, ..., 0].cpu().numpy(), ref_mask[k]), i
+
+
+def test_c5_at_per_gpu_share_sampled_frames_match_oracle(api, ctx, oracle):
+    """BASELINE configs[4] at the size bench.py times on one GPU (`--workload c5`, and the `motion_apply` leg): one GPU's
+    share of the 8-GPU run = 64 x 3840x2160, Flow similarity + expand -> Motion Apply (expand, bilinear, blur 0.5,
+    Ultra = 33 samples) on the original frames, device-resident.  All 63 pairs of the Flow stage against the oracle; the
+    Flow node's warped frames {0, 31, 63} and masks bit-exact against the oracle warp of the reported matrices; the
+    blurred frames {0, 1, 31, 62, 63} bit-exact from 2-frame oracle windows on the expanded canvas (a blurred frame needs
+    its own pixels, its own and its successor's matrix -- the last frame its predecessor's: motion_apply.py:125-134; the
+    canvas and its shift come from ALL the clip's matrices: motion_apply.py:288-294)."""
+    import torch
+
+    import bench
+    from vstab_amd import apply_pipeline as ap
+
+    n, h, w = 64, 2160, 3840
+    frames = bench.synth_clip(n, 0, h, w, torch.device("cuda"))
+    res = api.fp._stabilize_frames(api.hm._normalize_video_input(frames), *bench.C5_FLOW_ARGS, ctx=ctx, keep_on_device=True)
+    meta = res.meta
+    ow, oh = meta["framing"]["expanded_size"]
+    assert tuple(res.frames.shape) == (n, oh, ow, 3) and ow > w and oh > h
+    host = frames.cpu().numpy()
+    check_flow_stage(api, oracle, host, meta, "similarity")
+    fm = np.array([e["applied_matrix"] for e in meta["stabilization_warp"]["per_frame"]], np.float32)
+    for i in (0, 31, 63):
+        ref, ref_mask, cnt = oracle.warp_clip(host[i:i + 1], fm[i:i + 1], (ow, oh), border=BORDER)
+        assert np.array_equal(res.frames[i].cpu().numpy(), ref[0]), i
+        assert np.array_equal(res.masks[i, ..., 0].cpu().numpy(), ref_mask[0]), i
+    del res
+    torch.cuda.empty_cache()
+    out = ap.apply_motion(api.hm._normalize_video_input(frames), meta, (127, 127, 127), ctx=ctx, keep_on_device=True, **bench.C5_APPLY)
+    ma = out.meta["motion_apply"]
+    ew, eh = ma["output_size"]
+    assert ma["framing_mode"] == "expand" and ma["motion_blur_samples"] == 33 and tuple(out.frames.shape) == (n, eh, ew, 3)
+    m64 = [np.array(e["matrix"], np.float64) for e in meta["motion_meta"]["per_frame"]]
+    mins, maxs = api.hm._compute_bounding_boxes(m64, w, h)
+    shift, size = api.hm._prepare_expand_transform(mins, maxs)
+    assert list(size) == [ew, eh]
+    expanded = np.stack([shift @ m for m in m64])
+    for i in (0, 1, 31, 62, 63):
+        lo = min(i, n - 2)
+        ref, ref_mask = oracle.warp_blur_clip(host[lo:lo + 2], expanded[lo:lo + 2], (ew, eh), 0.5, 33, interp="bilinear", border=BORDER)
+        k = i - lo
+        assert np.array_equal(out.frames[i].cpu().numpy(), ref[k]), i
+        assert np.array_equal(out.masks[i, ..., 0].cpu().numpy(), ref_mask[k]), i
