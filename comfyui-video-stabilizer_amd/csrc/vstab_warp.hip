@@ -446,6 +446,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
 
     // ---- the source window this tile can touch, over all samples
     bool fast = G::FAST && a.blur_fast != 0;
+    bool inside = false;   // the staged window lies inside the source: no tap of the tile meets the border
     int ox = 0, oy = 0, fw = 0;
     if (fast) {
         bool ok = true;
@@ -482,14 +483,22 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             oy = s_box[1] - G::LEAD - 1;
             fw = s_box[2] - s_box[0] + G::TAPS + 2;
             const int fh = s_box[3] - s_box[1] + G::TAPS + 2;
-            fast = ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh && fw * fh <= G::FOOT_TEXELS;   // uniform
+            fast = fw * fh <= G::FOOT_TEXELS;   // uniform
+            inside = ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
             if (fast) {
-                // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row
+                // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row.  A
+                // window that leaves the source (the ring of tiles along the content's edge) is filled with the border
+                // colour there: BORDER_CONSTANT replaces a tap outside the source by the border value, tap by tap.
                 typedef float f3_t __attribute__((ext_vector_type(3), aligned(4)));
                 for (int i = threadIdx.x; i < fw * fh; i += NT) {
                     const int r = i / fw, c = i - r * fw;
-                    const f3_t v = *reinterpret_cast<const f3_t*>(S + ((unsigned)(oy + r) * (unsigned)a.sw + (unsigned)(ox + c)) * 3u);
-                    s_foot[i] = f4_t{v.x, v.y, v.z, 0.f};
+                    const int gy = oy + r, gx = ox + c;
+                    f4_t e = f4_t{a.b0, a.b1, a.b2, 0.f};
+                    if (inside || ((unsigned)gx < (unsigned)a.sw && (unsigned)gy < (unsigned)a.sh)) {
+                        const f3_t v = *reinterpret_cast<const f3_t*>(S + ((unsigned)gy * (unsigned)a.sw + (unsigned)gx) * 3u);
+                        e = f4_t{v.x, v.y, v.z, 0.f};
+                    }
+                    s_foot[i] = e;
                 }
             }
             __syncthreads();
@@ -501,7 +510,91 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
 #pragma unroll
     for (int p = 0; p < TILE_PX; p++) { acc[p][0] = acc[p][1] = acc[p][2] = 0.f; cov[p] = 0.f; }
 
-    if (active && fast) {
+    if (active && fast && !inside) {
+        // ---- the STAGED loop for a tile whose window leaves the source: the taps still come from LDS (border-filled),
+        // and what the interior loop may leave out is put back per pixel-sample -- the three cases of cv::remap with
+        // BORDER_CONSTANT (all taps inside: the plain sums; no tap inside: the border value itself, not a weighted sum of
+        // sixteen copies of it; otherwise bilinear: the same sums over the border-filled taps, bicubic: OpenCV's separate
+        // formula border + sum over the VALID taps of (tap - border) * weight), and the nearest-neighbour coverage test.
+        // Round 3 ran these tiles (the ring along the content's edge: ~10 % of a crop_and_pad clip's tiles) through the
+        // general loop, at the L1-bound rate of round 2.
+        const int xb = block_origin(x0);
+        const double dy = (double)y, dxb = (double)xb;
+        double dx1[TILE_PX];
+#pragma unroll
+        for (int p = 0; p < TILE_PX; p++) dx1[p] = (double)((p < npx ? x0 + p * TILE_TX : x0) - xb);
+        const int tap0 = (oy + G::LEAD) * fw + ox + G::LEAD;
+        for (int k = 0; k < nxf; k++) {
+            const WarpXform* __restrict__ xf = xf0 + k;
+            const double m0 = xf->m[0], m3 = xf->m[3], wq = xf->wq, wn = xf->wn;
+            const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
+            const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+#pragma unroll
+            for (int p = 0; p < TILE_PX; p++) {
+                const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
+                const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
+                const int sx = X >> 5, sy = Y >> 5;     // |sx|, |sy| < 2^15 (corner test): sat_short is the identity
+                const int fx = X & 31, fy = Y & 31;
+                const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)(sy - oy - G::LEAD), (unsigned)fw) + (sx - ox - G::LEAD));
+                (void)tap0;
+                float vr, vg, vb;
+                if (INTERP == VSTAB_INTERP_BICUBIC) {
+                    const f4_t cxv = reinterpret_cast<const f4_t*>(s_cub)[fx], cyv = reinterpret_cast<const f4_t*>(s_cub)[fy];
+                    const float cx[4] = {cxv.x, cxv.y, cxv.z, cxv.w}, cy[4] = {cyv.x, cyv.y, cyv.z, cyv.w};
+                    const int bx0 = sx - 1, by0 = sy - 1;
+                    const unsigned width1 = (unsigned)(a.sw - 3 > 0 ? a.sw - 3 : 0), height1 = (unsigned)(a.sh - 3 > 0 ? a.sh - 3 : 0);
+                    if ((unsigned)bx0 < width1 && (unsigned)by0 < height1) {
+                        float sr = 0.f, sg = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const f4_t t0 = T[i * fw], t1 = T[i * fw + 1], t2 = T[i * fw + 2], t3 = T[i * fw + 3];
+                            const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+                            const float tr_ = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
+                            const float tg_ = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
+                            const float tb_ = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
+                            if (i == 0) { sr = tr_; sg = tg_; sb = tb_; }
+                            else { sr += tr_; sg += tg_; sb += tb_; }
+                        }
+                        vr = sr; vg = sg; vb = sb;
+                    } else if (bx0 >= a.sw || bx0 + 4 <= 0 || by0 >= a.sh || by0 + 4 <= 0) {
+                        vr = a.b0; vg = a.b1; vb = a.b2;
+                    } else {
+                        float sr = a.b0, sg = a.b1, sb = a.b2;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int yy = by0 + i;
+                            if (yy < 0 || yy >= a.sh) continue;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int xx = bx0 + j;
+                                if (xx < 0 || xx >= a.sw) continue;
+                                const f4_t v = T[i * fw + j];
+                                const float w = cy[i] * cx[j];
+                                sr += (v.x - a.b0) * w;
+                                sg += (v.y - a.b1) * w;
+                                sb += (v.z - a.b2) * w;
+                            }
+                        }
+                        vr = sr; vg = sg; vb = sb;
+                    }
+                } else {
+                    const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
+                    const f4_t w = reinterpret_cast<const f4_t*>(s_tab)[fy * 32 + fx];
+                    const bool none = sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0;
+                    vr = t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
+                    vg = t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
+                    vb = t00.z * w.x + t01.z * w.y + t10.z * w.z + t11.z * w.w;
+                    if (none) { vr = a.b0; vg = a.b1; vb = a.b2; }
+                }
+                acc[p][0] += vr; acc[p][1] += vg; acc[p][2] += vb;
+                if (WITH_MASK) {
+                    const int nx = round_small(Xn * wn), ny = round_small(Yn * wn);
+                    cov[p] += ((unsigned)nx < (unsigned)a.sw && (unsigned)ny < (unsigned)a.sh) ? 1.f : 0.f;
+                }
+                if (INTERP == VSTAB_INTERP_BICUBIC) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (active && fast) {
         const int xb = block_origin(x0);                 // == block_origin(x0 + TILE_TX): blur_fast
         const double dy = (double)y, dxb = (double)xb;
         // a pixel of this thread beyond the right edge (ragged last tile) re-evaluates pixel 0 instead of being skipped:

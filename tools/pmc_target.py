@@ -27,6 +27,16 @@ def _settled(t):
 
 frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
 say("clip ready")
+# the library's stages once, one at a time with a host synchronisation and a line after each: a pass that is killed at its
+# time limit shows which stage it was in (the two earlier incidents left only "clip ready")
+work = hm._working_estimation_size(1920, 1080)
+gray = ctx.gray_downscale(frames, work); ctx.synchronize(); say("stage gray done")
+_, grid = ctx.dis_flow_batch(gray, sample_step=fp.SAMPLE_STEP, want_full=False, want_grid=True); ctx.synchronize(); say("stage dis done")
+table = ctx.sample_fit_batch(grid, fp.SAMPLE_STEP, "similarity"); say("stage fit done")
+plan = fp.plan_stabilization(ctx, table, (1920, 1080), 256, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0, 16.0)
+d_, m_, c_ = ctx.warp_batch(frames, plan.final_matrices, (1920, 1080), border=hm.border_value((127, 127, 127)), want_mask=True, want_count=True)
+ctx.synchronize(); say("stage warp done")
+del gray, grid, d_, m_, c_
 for k in range(2):
     r = fp._stabilize_frames(hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
     del r
