@@ -300,9 +300,12 @@ int vstab_params_to_matrices(const double* params, int count, int mode, float* m
 }
 
 // _compute_bounding_boxes (stabilizer_utils.py:1010-1034) for a whole clip: the four corners (0,0) (w,0) (0,h) (w,h) through
-// each matrix in fp64 (`m @ corners` with m cast to fp64: products in corner order, summed left to right -- what NumPy's
-// mixed-dtype matmul evaluates, checked bit for bit in tests/test_abi_cpu.py), divided by the third row, min / max per axis
-// with NumPy's NaN-propagating minimum / maximum.
+// each matrix in fp64 (`m @ corners` with m cast to fp64: products in corner order, summed left to right, unfused),
+// divided by the third row, min / max per axis with NumPy's NaN-propagating minimum / maximum.  Equal to THIS container's
+// NumPy bit for bit (tests/test_abi_cpu.py); the reference's `matrix @ corners` goes through whatever BLAS its NumPy was
+// built with, and a dgemm micro-kernel that fuses multiply-adds can differ from this in the last bit of the (w, h) corner:
+// parity with the reference is BLAS-dependent to 1 ulp there (it enters the meta as min_content_ratio / safe_region_*).
+// The end-to-end fixtures produced by the reference's own run (tests/test_e2e_golden_*.py) are the arbiter.
 static inline double np_minimum(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
 static inline double np_maximum(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 

@@ -383,10 +383,13 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 //     halve the blocks per CU for 16 of ~140 instructions.
 template <int INTERP, int SUBPIX>
 struct BlurGeom {
-    static constexpr bool FAST = SUBPIX == VSTAB_SUBPIX_Q5;
+    // the staged loops exist for every sampler; `exact` (the OpenCV >= 4.11 bilinear form: float32 coordinates, lerp
+    // arithmetic) runs the border-capable one for all of its staged tiles
+    static constexpr bool FAST = true;
+    static constexpr bool EXACT = SUBPIX == VSTAB_SUBPIX_EXACT;
     static constexpr bool BICUBIC = INTERP == VSTAB_INTERP_BICUBIC;
     static constexpr int NT = 512;                                    // 64 x 16 output pixels
-    static constexpr int TAB_FLOATS = (FAST && !BICUBIC) ? 32 * 32 * 4 : 0;   // bilinear product table
+    static constexpr int TAB_FLOATS = (!EXACT && !BICUBIC) ? 32 * 32 * 4 : 0;   // bilinear product table
     static constexpr int FOOT_TEXELS = !FAST ? 0 : (BICUBIC ? 4864 : 2304);   // staged source window (float4 per texel)
     static constexpr int TAPS = BICUBIC ? 4 : 2, LEAD = BICUBIC ? 1 : 0;      // taps per axis, taps left of / above (sx, sy)
     // LDS per block: bicubic 76 KB + 0.5 KB (two blocks per CU), bilinear 16 + 36 + 0.5 KB (three)
@@ -463,6 +466,18 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             const double Xq = Xn * xf->wq, Yq = Yn * xf->wq;
             ok = xf->affine != 0 && __builtin_fabs(Xq) < 9.0e5 && __builtin_fabs(Yq) < 9.0e5;   // NaN compares false
             if (ok) { bx0 = bx1 = round_small(Xq) >> 5; by0 = by1 = round_small(Yq) >> 5; }
+            if (G::EXACT && ok) {
+                // the exact sampler's own source position of this corner (float32 chain, monotone in x and in y for an
+                // affine sample: every operation is correctly rounded and the divisor is the constant m8)
+                float mf[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
+                const float w = cx_ * mf[6] + cy_ * mf[7] + mf[8];
+                const float fsx = (cx_ * mf[0] + cy_ * mf[1] + mf[2]) / w, fsy = (cx_ * mf[3] + cy_ * mf[4] + mf[5]) / w;
+                ok = __builtin_fabsf(fsx) < 28000.f && __builtin_fabsf(fsy) < 28000.f;
+                if (ok) { bx0 = bx1 = (int)__builtin_floorf(fsx); by0 = by1 = (int)__builtin_floorf(fsy); }
+                else { bx0 = by0 = 0x7fffffff; bx1 = by1 = (int)0x80000000; }
+            }
         }
         // bounding box: butterfly over the wavefront (idle lanes hold the neutral elements), one LDS atomic set per wavefront
         if ((int)(threadIdx.x & ~63u) < 4 * nxf) {
@@ -484,7 +499,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             fw = s_box[2] - s_box[0] + G::TAPS + 2;
             const int fh = s_box[3] - s_box[1] + G::TAPS + 2;
             fast = fw * fh <= G::FOOT_TEXELS;   // uniform
-            inside = ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
+            inside = !G::EXACT && ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
             if (fast) {
                 // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row.  A
                 // window that leaves the source (the ring of tiles along the content's edge) is filled with the border
@@ -494,7 +509,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                     const int r = i / fw, c = i - r * fw;
                     const int gy = oy + r, gx = ox + c;
                     f4_t e = f4_t{a.b0, a.b1, a.b2, 0.f};
-                    if (inside || ((unsigned)gx < (unsigned)a.sw && (unsigned)gy < (unsigned)a.sh)) {
+                    if ((unsigned)gx < (unsigned)a.sw && (unsigned)gy < (unsigned)a.sh) {
                         const f3_t v = *reinterpret_cast<const f3_t*>(S + ((unsigned)gy * (unsigned)a.sw + (unsigned)gx) * 3u);
                         e = f4_t{v.x, v.y, v.z, 0.f};
                     }
@@ -529,16 +544,37 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             const double m0 = xf->m[0], m3 = xf->m[3], wq = xf->wq, wn = xf->wn;
             const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
             const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+            float mf[9];
+            if (G::EXACT) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) mf[i] = (float)xf->m[i];
+            }
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) {
                 const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
                 const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
-                const int sx = X >> 5, sy = Y >> 5;     // |sx|, |sy| < 2^15 (corner test): sat_short is the identity
+                int sx = X >> 5, sy = Y >> 5;           // |sx|, |sy| < 2^15 (corner test): sat_short is the identity
                 const int fx = X & 31, fy = Y & 31;
+                float ax = 0.f, ay = 0.f;
+                if (G::EXACT) {   // sample_exact's coordinates: float32, no 1/32-px quantisation
+                    const int x = p < npx ? x0 + p * TILE_TX : x0;
+                    const float w = x * mf[6] + y * mf[7] + mf[8];
+                    const float fsx = (x * mf[0] + y * mf[1] + mf[2]) / w, fsy = (x * mf[3] + y * mf[4] + mf[5]) / w;
+                    sx = (int)__builtin_floorf(fsx); sy = (int)__builtin_floorf(fsy);
+                    ax = fsx - sx; ay = fsy - sy;
+                }
                 const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)(sy - oy - G::LEAD), (unsigned)fw) + (sx - ox - G::LEAD));
-                (void)tap0;
+                (void)tap0; (void)fx; (void)fy;
                 float vr, vg, vb;
-                if (INTERP == VSTAB_INTERP_BICUBIC) {
+                if (G::EXACT) {
+                    const f4_t p00 = T[0], p01 = T[1], p10 = T[fw], p11 = T[fw + 1];
+                    const bool none = sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0;
+                    float v0, v1;
+                    v0 = p00.x + ax * (p01.x - p00.x); v1 = p10.x + ax * (p11.x - p10.x); vr = v0 + ay * (v1 - v0);
+                    v0 = p00.y + ax * (p01.y - p00.y); v1 = p10.y + ax * (p11.y - p10.y); vg = v0 + ay * (v1 - v0);
+                    v0 = p00.z + ax * (p01.z - p00.z); v1 = p10.z + ax * (p11.z - p10.z); vb = v0 + ay * (v1 - v0);
+                    if (none) { vr = a.b0; vg = a.b1; vb = a.b2; }
+                } else if (INTERP == VSTAB_INTERP_BICUBIC) {
                     const f4_t cxv = reinterpret_cast<const f4_t*>(s_cub)[fx], cyv = reinterpret_cast<const f4_t*>(s_cub)[fy];
                     const float cx[4] = {cxv.x, cxv.y, cxv.z, cxv.w}, cy[4] = {cyv.x, cyv.y, cyv.z, cyv.w};
                     const int bx0 = sx - 1, by0 = sy - 1;
@@ -731,15 +767,24 @@ int launch_blur(WarpArgs a, bool with_mask, hipStream_t st)
     // the prologue (corner classification, staging, two barriers) is amortised over the samples: measured break-even
     // S = 4 for bilinear (S = 3: 2.00 vs 1.86 ms per 64 x 1080p; S = 5: 2.38 vs 2.50), below 3 for bicubic
     if (INTERP == VSTAB_INTERP_BILINEAR && a.nxf_per_frame < 4) a.blur_fast = 0;
-    if (const char* e = getenv("VSTAB_BLUR_FAST")) a.blur_fast = a.blur_fast && atoi(e) != 0;   // 0: general loop everywhere (tests, A/B)
-    const size_t lds = G::LDS_BYTES;
-    if (with_mask) {
-        if (lds > 64 * 1024) VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, true>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
-    } else {
-        if (lds > 64 * 1024) VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, false>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
+    // 0: general loop everywhere (tests toggle it inside one process, so it is read per launch: ~0.1 us against a kernel
+    // of milliseconds)
+    if (const char* e = getenv("VSTAB_BLUR_FAST")) a.blur_fast = a.blur_fast && atoi(e) != 0;
+    // The staged window needs more than the default 64 KB of dynamic LDS for bicubic (76.5 KB): asked for ONCE per kernel
+    // instance; a device (or runtime) that refuses it gets the general loop everywhere with the small allocation instead of
+    // an error -- the staged path is an optimisation, the general loop is the definition.
+    static const bool big_lds_mask = G::LDS_BYTES <= 64 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+    static const bool big_lds_plain = G::LDS_BYTES <= 64 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+    size_t lds = G::LDS_BYTES;
+    if (!(with_mask ? big_lds_mask : big_lds_plain)) {
+        (void)hipGetLastError();
+        a.blur_fast = 0;
+        lds = sizeof(float) * ((size_t)G::TAB_FLOATS + 32 * 4);
     }
+    if (with_mask) hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, true>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
+    else hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, false>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }

@@ -308,3 +308,25 @@ def test_blur_staged_path_under_extreme_maps(ctx, oracle, kind, interp):
     ref, ref_mask = oracle.warp_blur_clip(frames, mats, (sw, sh), 0.6, 9, interp=interp, border=BORDER)
     dst, mask = ctx.warp_blur_batch(frames, mats, (sw, sh), 0.6, 9, interp=interp, border=BORDER)
     assert np.array_equal(dst.cpu().numpy(), ref, equal_nan=True) and np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+@pytest.mark.parametrize("kind,samples", [("similarity", 9), ("translation", 33), ("similarity", 5)])
+def test_blur_exact_subpixel_mode_staged_path_matches_oracle(ctx, oracle, kind, samples):
+    """`subpix="exact"` (the OpenCV >= 4.11 bilinear warp: float32 coordinates, no 1/32-px quantisation) in the S-sample
+    blur: since round 4 its tiles are staged in LDS like the default sampler's (border-capable loop), instead of falling to
+    the general loop at 4K / S = 33.  Bit-exact against the oracle's exact mode, content edges and padded regions included;
+    and the same bits as the general loop forced everywhere."""
+    import os
+
+    h, w = 270, 480
+    frames = synth_frames(3, h, w, seed=21)
+    mats = make_matrices(3, w, h, kind, seed=4)
+    ref, ref_mask = oracle.warp_blur_clip(frames, mats, (w, h), 0.5, samples, interp="bilinear", border=BORDER, subpix="exact")
+    dst, mask = ctx.warp_blur_batch(frames, mats, (w, h), 0.5, samples, interp="bilinear", border=BORDER, subpix="exact")
+    assert np.array_equal(dst.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), ref_mask)
+    os.environ["VSTAB_BLUR_FAST"] = "0"
+    try:
+        gen, gen_mask = ctx.warp_blur_batch(frames, mats, (w, h), 0.5, samples, interp="bilinear", border=BORDER, subpix="exact")
+    finally:
+        del os.environ["VSTAB_BLUR_FAST"]
+    assert bool((gen == dst).all()) and bool((gen_mask == mask).all())
