@@ -452,7 +452,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
     bool inside = false;   // the staged window lies inside the source: no tap of the tile meets the border
     int ox = 0, oy = 0, fw = 0;
     if (fast) {
-        bool ok = true;
+        bool ok = true, any_persp = false;
         int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
         if ((int)threadIdx.x < 4 * nxf) {
             const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
@@ -463,8 +463,22 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             const double dxb = (double)xb, dyc = (double)cy_, dx1 = (double)(cx_ - xb);
             const double Xn = (xf->m[0] * dxb + xf->m[1] * dyc + xf->m[2]) + xf->m[0] * dx1;
             const double Yn = (xf->m[3] * dxb + xf->m[4] * dyc + xf->m[5]) + xf->m[3] * dx1;
-            const double Xq = Xn * xf->wq, Yq = Yn * xf->wq;
-            ok = xf->affine != 0 && __builtin_fabs(Xq) < 9.0e5 && __builtin_fabs(Yq) < 9.0e5;   // NaN compares false
+            // A sample with a perspective row (Flow in perspective mode -> Motion Apply: BASELINE C3) maps the tile onto a
+            // convex quadrilateral as long as its denominator W = m6 x + m7 y + m8 keeps one sign over the tile -- W is
+            // affine in (x, y), so that is a test of the four corners -- and a convex quadrilateral lies inside the
+            // bounding box of its corners.  The kernel's rounded coordinates can leave that box by one 1/32-px unit at
+            // most (fp64 evaluation error ~1e-10 of a unit), which the window's one-texel margin absorbs.
+            double wq_c = xf->wq;
+            bool w_ok = true;
+            if (!xf->affine) {
+                const double W = (xf->m[6] * dxb + xf->m[7] * dyc + xf->m[8]) + xf->m[6] * dx1;
+                const bool pos = W > 0.0;
+                w_ok = !G::EXACT && W != 0.0 && W == W && (__shfl_xor((int)pos, 1) == (int)pos) && (__shfl_xor((int)pos, 2) == (int)pos);
+                wq_c = 32.0 * ((W != 0.0) ? 1.0 / W : 0.0);
+                any_persp = true;
+            }
+            const double Xq = Xn * wq_c, Yq = Yn * wq_c;
+            ok = w_ok && __builtin_fabs(Xq) < 9.0e5 && __builtin_fabs(Yq) < 9.0e5;   // NaN compares false
             if (ok) { bx0 = bx1 = round_small(Xq) >> 5; by0 = by1 = round_small(Yq) >> 5; }
             if (G::EXACT && ok) {
                 // the exact sampler's own source position of this corner (float32 chain, monotone in x and in y for an
@@ -492,6 +506,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             }
         }
         fast = __syncthreads_and(ok) != 0;
+        const bool persp = __syncthreads_or(any_persp) != 0;   // uniform: some sample of this frame has a perspective row
         if (fast) {
             // taps of (sx, sy): columns sx - LEAD .. sx - LEAD + TAPS - 1; one texel of margin on every side
             ox = s_box[0] - G::LEAD - 1;
@@ -499,7 +514,8 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             fw = s_box[2] - s_box[0] + G::TAPS + 2;
             const int fh = s_box[3] - s_box[1] + G::TAPS + 2;
             fast = fw * fh <= G::FOOT_TEXELS;   // uniform
-            inside = !G::EXACT && ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
+            // (perspective samples and the exact sampler take the border-capable loop: it carries their coordinate forms)
+            inside = !G::EXACT && !persp && ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
             if (fast) {
                 // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row.  A
                 // window that leaves the source (the ring of tiles along the content's edge) is filled with the border
@@ -541,9 +557,11 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
         const int tap0 = (oy + G::LEAD) * fw + ox + G::LEAD;
         for (int k = 0; k < nxf; k++) {
             const WarpXform* __restrict__ xf = xf0 + k;
-            const double m0 = xf->m[0], m3 = xf->m[3], wq = xf->wq, wn = xf->wn;
+            const double m0 = xf->m[0], m3 = xf->m[3], m6 = xf->m[6];
+            const bool aff = xf->affine != 0;
             const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
             const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+            const double W0 = m6 * dxb + xf->m[7] * dy + xf->m[8];
             float mf[9];
             if (G::EXACT) {
 #pragma unroll
@@ -552,6 +570,12 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) {
                 const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
+                double wq = xf->wq, wn = xf->wn;
+                if (!aff) {   // the general loop's per-pixel denominator (uniform branch: a property of the sample)
+                    const double W = W0 + m6 * dx1[p];
+                    wn = (W != 0.0) ? 1.0 / W : 0.0;
+                    wq = 32.0 * wn;
+                }
                 const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
                 int sx = X >> 5, sy = Y >> 5;           // |sx|, |sy| < 2^15 (corner test): sat_short is the identity
                 const int fx = X & 31, fy = Y & 31;
