@@ -244,7 +244,7 @@ def cpu_baseline(frames_host: np.ndarray, threads: int, keep_outputs: bool = Fal
                   "frames": warped, "masks": mask, "counts": counts, "gray": gray, "flow": flow}
 
 
-def cv2_leg(ctx, torch, frames_dev, threads: int, max_frames: int) -> dict:
+def cv2_leg(ctx, torch, frames_dev, threads: int, max_frames: int, allow_standin: bool = False) -> dict:
     """The real-OpenCV tier, decided at run time: returns {"probe": ...} always,
     plus -- when a real `cv2` imports -- "baseline" (the reference's own cv2 calls timed on this host, kind "opencv") and
     "parity" (the HIP path against them on the same frames: gray levels, flow end-point error, fitted / final matrices,
@@ -253,7 +253,7 @@ def cv2_leg(ctx, torch, frames_dev, threads: int, max_frames: int) -> dict:
 
     info = cv2_tier.probe()
     out = {"probe": info}
-    if info["cv2"] == "absent" or info.get("standin"):
+    if info["cv2"] == "absent" or (info.get("standin") and not allow_standin):   # allow_standin: tests of this function only
         return out
     import __graft_entry__ as graft
 
@@ -267,7 +267,8 @@ def cv2_leg(ctx, torch, frames_dev, threads: int, max_frames: int) -> dict:
     sample = sample_dev.cpu().numpy()
     h, w = sample.shape[1:3]
     base, ref = cpu_baseline(sample, threads, keep_outputs=True, provider=tier)
-    base.update({"cv2_version": info["cv2"], "cv2_threads": int(tier.cv2.getNumThreads()), "ipp": info.get("ipp")})
+    base.update({"cv2_version": info["cv2"], "cv2_threads": int(tier.cv2.getNumThreads()) if hasattr(tier.cv2, "getNumThreads") else None,
+                 "ipp": info.get("ipp")})
     out["baseline"] = base
     # ---- parity: the HIP path on the same n frames
     res = fp._stabilize_frames(hm._normalize_video_input(sample_dev), *FLOW_ARGS, ctx=ctx, keep_on_device=True)
