@@ -378,9 +378,22 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a)
 //   * The staged loop has no bounds tests, no short saturation (no-ops in the interior) and no coverage arithmetic
 //     (all S samples covered: mask = 1 - S/S = 0, the float the general loop produces); the f64 block-origin terms
 //     X0, Y0 are formed once per thread and sample, not per pixel; taps are 16-byte LDS reads at a 16-byte lane stride.
-//   * bilinear: the four tap weights come from the 32 x 32 table of PRODUCTS in LDS (what OpenCV's remap reads:
-//     initInterTab2D), 16 KB; bicubic keeps the 1-D table + 16 products per sample: its 64 KB product table would
-//     halve the blocks per CU for 16 of ~140 instructions.
+//   * bilinear: the four tap weights are formed in registers by the expressions of OpenCV's 32 x 32 product table
+//     (initInterTab2D; bilinear_weights above -- round 3 read an LDS copy of the table: 35 % bank conflicts); bicubic keeps
+//     the 1-D table in LDS + 16 products per sample: its 64 KB product table would halve the blocks per CU for 16 of ~140
+//     instructions.
+// The four bilinear tap weights of a 1/32-px fraction pair, formed in registers by the expressions that fill OpenCV's 32 x 32
+// table of products (initInterTab2D) -- the same float32 products.  Round 3 read them from a copy of that table in LDS: its
+// random 16-B reads were 35 % bank conflicts of a loop that keeps the LDS array 73 % busy; ten VALU instructions instead:
+// 16 x 4K x 33 samples 5.87 -> 5.55 ms (profiles/r04_blur_kernel.md).
+typedef float blur_f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ blur_f4_t bilinear_weights(int fx, int fy)
+{
+    const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1;
+    const float wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
+    return blur_f4_t{wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+}
+
 template <int INTERP, int SUBPIX>
 struct BlurGeom {
     // the staged loops exist for every sampler; `exact` (the OpenCV >= 4.11 bilinear form: float32 coordinates, lerp
@@ -389,11 +402,10 @@ struct BlurGeom {
     static constexpr bool EXACT = SUBPIX == VSTAB_SUBPIX_EXACT;
     static constexpr bool BICUBIC = INTERP == VSTAB_INTERP_BICUBIC;
     static constexpr int NT = 512;                                    // 64 x 16 output pixels
-    static constexpr int TAB_FLOATS = (!EXACT && !BICUBIC) ? 32 * 32 * 4 : 0;   // bilinear product table
     static constexpr int FOOT_TEXELS = !FAST ? 0 : (BICUBIC ? 4864 : 2304);   // staged source window (float4 per texel)
     static constexpr int TAPS = BICUBIC ? 4 : 2, LEAD = BICUBIC ? 1 : 0;      // taps per axis, taps left of / above (sx, sy)
-    // LDS per block: bicubic 76 KB + 0.5 KB (two blocks per CU), bilinear 16 + 36 + 0.5 KB (three)
-    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)TAB_FLOATS + 32 * 4 + (size_t)FOOT_TEXELS * 4);
+    // LDS per block: bicubic 76 KB + 0.5 KB (two blocks per CU), bilinear 36 + 0.5 KB (four)
+    static constexpr size_t LDS_BYTES = sizeof(float) * (32 * 4 + (size_t)FOOT_TEXELS * 4);
 };
 
 // amdgpu_waves_per_eu(4): at most 128 VGPRs, so that two 512-thread bicubic blocks share a CU.
@@ -406,23 +418,14 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
     using G = BlurGeom<INTERP, SUBPIX>;
     constexpr int NT = G::NT, TILE_TX = 32, TILE_W = TILE_TX * TILE_PX, TILE_H = NT / TILE_TX;
     typedef float f4_t __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float s_mem[];   // [product table][1-D cubic table][staged window]
-    float* s_tab = s_mem;
-    float* s_cub = s_mem + G::TAB_FLOATS;
-    f4_t* s_foot = reinterpret_cast<f4_t*>(s_mem + G::TAB_FLOATS + 32 * 4);
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];   // [1-D cubic table][staged window]
+    float* s_cub = s_mem;
+    f4_t* s_foot = reinterpret_cast<f4_t*>(s_mem + 32 * 4);
     __shared__ int s_box[4];   // min sx, min sy, max sx, max sy over corners x samples
     const float* cub_tab = nullptr;
     if (INTERP == VSTAB_INTERP_BICUBIC) {
         if (threadIdx.x < 32) cubic_coeffs((int)threadIdx.x, s_cub + threadIdx.x * 4);
         cub_tab = s_cub;
-    }
-    if (G::TAB_FLOATS) {
-        for (int e = threadIdx.x; e < 1024; e += NT) {
-            const int fy = e >> 5, fx = e & 31;
-            const float wx1 = fx * (1.f / 32), wx0 = 1.f - wx1;
-            const float wy1 = fy * (1.f / 32), wy0 = 1.f - wy1;
-            reinterpret_cast<f4_t*>(s_tab)[e] = f4_t{wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
-        }
     }
     if (threadIdx.x == 0) { s_box[0] = s_box[1] = 0x7fffffff; s_box[2] = s_box[3] = (int)0x80000000; }
     __syncthreads();
@@ -588,7 +591,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                     ax = fsx - sx; ay = fsy - sy;
                 }
                 const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)(sy - oy - G::LEAD), (unsigned)fw) + (sx - ox - G::LEAD));
-                (void)tap0; (void)fx; (void)fy;
+                (void)tap0;
                 float vr, vg, vb;
                 if (G::EXACT) {
                     const f4_t p00 = T[0], p01 = T[1], p10 = T[fw], p11 = T[fw + 1];
@@ -639,7 +642,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                     }
                 } else {
                     const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
-                    const f4_t w = reinterpret_cast<const f4_t*>(s_tab)[fy * 32 + fx];
+                    const f4_t w = bilinear_weights(fx, fy);
                     const bool none = sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0;
                     vr = t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
                     vg = t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
@@ -693,7 +696,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                     __builtin_amdgcn_sched_barrier(0);   // one pixel's 16 taps at a time: both in flight need > 128 VGPRs (spills)
                 } else {
                     const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
-                    const f4_t w = reinterpret_cast<const f4_t*>(s_tab)[fy * 32 + fx];
+                    const f4_t w = bilinear_weights(fx, fy);
                     acc[p][0] += t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
                     acc[p][1] += t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
                     acc[p][2] += t00.z * w.x + t01.z * w.y + t10.z * w.z + t11.z * w.w;
@@ -805,7 +808,7 @@ int launch_blur(WarpArgs a, bool with_mask, hipStream_t st)
     if (!(with_mask ? big_lds_mask : big_lds_plain)) {
         (void)hipGetLastError();
         a.blur_fast = 0;
-        lds = sizeof(float) * ((size_t)G::TAB_FLOATS + 32 * 4);
+        lds = sizeof(float) * 32 * 4;
     }
     if (with_mask) hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, true>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
     else hipLaunchKernelGGL((warp_blur_kernel<INTERP, SUBPIX, false>), dim3((unsigned)blocks), dim3(G::NT), lds, st, a, a.xf);
