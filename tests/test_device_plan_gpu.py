@@ -189,3 +189,39 @@ def test_sticky_mode_on_the_device_equals_the_host_walk(ctx, pkg, mode):
         assert np.abs(final_dev.astype(np.float64) - plan.final_matrices).max() < 1e-12, (mode, case)
         if case < 4:
             assert np.array_equal(final_dev.view(np.uint32), plan.final_matrices.view(np.uint32)), (mode, case)
+
+
+def test_plan_kernel_reads_a_gathered_table_as_the_all_gather_leaves_it(ctx, pkg):
+    """Multi-GPU layout: the receive buffer of the ranks' all-gather holds one block of `rows` records rows per rank of which
+    the first pairs_of_rank are valid (rank 0 has one pair fewer than its frames; a rank without frames has none).  The plan
+    formed from that buffer through the segment table equals the plan formed from the contiguous table, bit for bit."""
+    import torch
+
+    from vstab_amd import distributed as vd
+    from vstab_amd import native
+
+    frames = _clip(ctx, 23, 960, 540, "similarity", amp=1.5)
+    pairs, work = _fits(ctx, frames, "similarity")
+    table = ctx.sample_fit_batch_end(pairs)                      # [22, 3] records
+    rec = 3 * native.FIT_DTYPE.itemsize
+    raw = table.view(np.uint8).reshape(pairs, rec)
+    args = ("similarity", (960, 540), work, 0.5, 16.0, 0.7, False)
+    dev = torch.from_numpy(raw.reshape(-1).copy()).to(ctx.device)
+    ctx.flow_plan_device(dev.data_ptr(), pairs, *args)
+    want = ctx.flow_plan_result(pairs + 1, 4)
+    for world in (2, 5, 8, 30):                                  # 30 ranks for 23 frames: ranks without frames
+        per_rank = vd.transition_counts(pairs + 1, world)
+        assert sum(per_rank) == pairs
+        rows = max(max(per_rank), 1)
+        flat = np.full((world, rows, rec), 0xAB, np.uint8)       # padding rows hold garbage: they must never be read
+        at = 0
+        for r, k in enumerate(per_rank):
+            flat[r, :k] = raw[at:at + k]
+            at += k
+        d = torch.from_numpy(flat).to(ctx.device)
+        ctx.flow_plan_device(d.data_ptr(), pairs, *args, seg_pairs=per_rank, seg_rows=rows)
+        got = ctx.flow_plan_result(pairs + 1, 4)
+        for a, b in zip(got, want):
+            assert np.array_equal(a.view(np.uint64 if a.dtype == np.float64 else np.uint32), b.view(np.uint64 if b.dtype == np.float64 else np.uint32)), world
+    with pytest.raises(native.VstabError, match="segments hold"):
+        ctx.flow_plan_device(dev.data_ptr(), pairs, *args, seg_pairs=[3, 4], seg_rows=4)
