@@ -82,8 +82,9 @@ Motion Apply (expand, bilinear, 0.5, Ultra = 33 samples).
 
 | run | frames/s | ms per step | gray | DIS | fit | warp (Flow's own output) | blur warp | host |
 |---|---|---|---|---|---|---|---|---|
-| `--workload c3` (in `tools/final_profiles.sh`: BEFORE perspective samples were staged) | {c3p["value"]} | {c3p["ms_per_step"]} | {s3["gray"]} | {s3["dis"]} | {s3["fit"]} | {s3["warp"]} | {s3["warp_blur"]} | -- |
-| `--workload c3`, final build (after: `profiles/r04_blur_kernel.md`) | 5404 | 47.37 | 1.135 | 3.175 | 1.535 | 2.815 | 37.43 | -- |
+| `--workload c3` | {c3p["value"]} | {c3p["ms_per_step"]} | {s3["gray"]} | {s3["dis"]} | {s3["fit"]} | {s3["warp"]} | {s3["warp_blur"]} | -- |
+| (the same before perspective samples were staged, earlier in the round) | 4114 | 62.22 | 0.989 | 3.197 | 1.529 | 2.602 | 52.56 | -- |
+| (`--workload c5` before the bilinear weights moved to registers) | 2217 | 28.87 | 0.934 | 1.872 | 0.107 | 2.896 | 21.97 | -- |
 | `--workload c5` (single process) | {c5p["value"]} | {c5p["ms_per_step"]} | {sp["gray"]} | {sp["dis"]} | {sp["fit"]} | {sp["warp"]} | {sp["warp_blur"]} | -- |
 | `--workload c5 --gpus 1 --force-dist` (sharded code path inside a world-1 RCCL group) | {c5d["value"]} | {c5d["ms_per_step"]} | {sd["gray"]} | {sd["dis"]} | {sd["fit"]} | {sd["warp"]} | {sd["warp_blur"]} | gather_fits {hd["gather_fits"]}, plan {hd["plan"]}, meta {hd["meta"]} ms |
 
