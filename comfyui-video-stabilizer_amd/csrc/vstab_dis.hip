@@ -851,6 +851,11 @@ constexpr int SOR_HALO = 2 * SOR_ITERS;   // one pixel of dependency per half-sw
 #define VSTAB_FUSED_T 1024
 #define VSTAB_SOR_NPT 5
 #endif
+#ifdef VSTAB_LEVEL_WAVES4   // tile sweeps with fewer threads per workgroup: keep 128 VGPRs so that two workgroups share a CU
+#define VSTAB_LEVEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))
+#else
+#define VSTAB_LEVEL_ATTR
+#endif
 constexpr int FUSED_T = VSTAB_FUSED_T;    // threads of the fused level kernel
 constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour (tile <= 2 * SOR_NPT * FUSED_T px)
 
@@ -872,7 +877,7 @@ constexpr int SOR_NPT = VSTAB_SOR_NPT;    // owned pixels per thread and colour 
 enum { LEVEL_FUSED = 0, LEVEL_PRE = 1, LEVEL_DERIV = 2, LEVEL_TILE = 4, LEVEL_MERGE = 5, LEVEL_UPSAMPLE = 6 };
 
 template <int MODE>
-__global__ __launch_bounds__(FUSED_T) void level_kernel(LevelArgs a)
+__global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelArgs a)
 {
 #ifdef VSTAB_FUSED_TRACE
     long long tprev_ = wall_clock64();
