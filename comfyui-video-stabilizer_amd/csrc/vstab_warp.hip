@@ -557,7 +557,6 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
         double dx1[TILE_PX];
 #pragma unroll
         for (int p = 0; p < TILE_PX; p++) dx1[p] = (double)((p < npx ? x0 + p * TILE_TX : x0) - xb);
-        const int tap0 = (oy + G::LEAD) * fw + ox + G::LEAD;
         for (int k = 0; k < nxf; k++) {
             const WarpXform* __restrict__ xf = xf0 + k;
             const double m0 = xf->m[0], m3 = xf->m[3], m6 = xf->m[6];
@@ -591,7 +590,6 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
                     ax = fsx - sx; ay = fsy - sy;
                 }
                 const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)(sy - oy - G::LEAD), (unsigned)fw) + (sx - ox - G::LEAD));
-                (void)tap0;
                 float vr, vg, vb;
                 if (G::EXACT) {
                     const f4_t p00 = T[0], p01 = T[1], p10 = T[fw], p11 = T[fw + 1];
