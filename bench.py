@@ -674,6 +674,9 @@ def main() -> int:
         # a collective that never completes (a rank that died) becomes an error after ten minutes, not a silent hang
         limit = datetime.timedelta(minutes=10)
         if args.rehearse_on_one_gpu:
+            # rehearse the form a real multi-GPU run takes (plan on the device from the gathered table), with its collectives
+            # through the host
+            os.environ.setdefault("VSTAB_SHARDED_DEVICE_PLAN", "force")
             dist.init_process_group(backend="gloo", timeout=limit)
         else:
             dist.init_process_group(backend="nccl", device_id=device, timeout=limit)

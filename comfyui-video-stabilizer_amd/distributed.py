@@ -27,6 +27,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+import os
 import time
 
 from . import host_math as hm
@@ -178,7 +179,10 @@ def stabilize_sharded(ctx, local_frames, total_frames: int, framing_mode: str, t
     t0 = time.perf_counter()
     # A function of the call's arguments and the backend only, hence the same on every rank: the ranks issue the same two
     # collectives either way (the fit records' all-gather has one shape in both forms).
-    if dev is not None and _fp.device_plan_applies(estimator, framing_mode, transform_mode, total_frames):
+    # VSTAB_SHARDED_DEVICE_PLAN=force: take the device-plan form under a gloo control plane too (its collectives then go
+    # through the host) -- how the multi-rank layout of that form is tested with several ranks on a one-GPU box.
+    forced = os.environ.get("VSTAB_SHARDED_DEVICE_PLAN", "") == "force"
+    if (dev is not None or forced) and _fp.device_plan_applies(estimator, framing_mode, transform_mode, total_frames):
         return _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_local, halo, size, working_size,
                                               framing_mode, transform_mode, camera_lock, strength, smooth, keep_fov, padding_rgb,
                                               fps_effective, fps_requested, group, stats, want_meta, check_value_range, t0)
@@ -268,7 +272,13 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
         raise ValueError(f"rank {rank} produced {pairs_local} transitions, expected {per_rank[rank]}")
     t0 = _lap(stats, "estimate", t0)
     flat = torch.empty((world, rows, rec_bytes), dtype=torch.uint8, device=ctx.device)
-    dist.all_gather_into_tensor(flat, send, group=group)
+    on_device = dist.get_backend(group) == "nccl"
+    if on_device:
+        dist.all_gather_into_tensor(flat, send, group=group)
+    else:   # gloo (tests of this form on a one-GPU box): the same bytes into the same places, through the host
+        parts = [torch.empty((rows, rec_bytes), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, send.cpu(), group=group)
+        flat.copy_(torch.stack(parts))
     # the host's copy of the gathered table is queued HERE, ahead of the plan kernel and the warp in stream order, into
     # page-locked memory with an event of its own: a plain .cpu() after the launches would wait for the warp to finish
     host_t = torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True)
@@ -301,7 +311,7 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
         sub = _fp.FlowPlan(plan.final_matrices[start:start + n_local], plan.output_size, {}, {}, {}, plan.framing_mode, size, fps_effective)
         mismatched = _fp._rewarp_mismatched(ctx, own, sub, final_dev[start:start + n_local], dst, mask, counts, padding_rgb)
     _fp.LAST_DEVICE_PLAN.update({"used": True, "mismatched_frames": mismatched})
-    fetch_counts = _start_gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=True)
+    fetch_counts = _start_gather_counts(counts, frame_counts(total_frames, world), group=group, on_device=on_device)
     meta = prepare_meta(plan) if want_meta else None  # host JSON work overlaps this rank's warp kernel and the collective
     t0 = _lap(stats, "meta", t0)
     all_counts = fetch_counts()
