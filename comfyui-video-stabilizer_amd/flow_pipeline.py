@@ -466,12 +466,17 @@ def _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, p
     """Frames whose device-plan matrix is not the host plan's, bit for bit, are warped again with the host's."""
     host = np.ascontiguousarray(plan.final_matrices, np.float32)
     bad = np.nonzero((host.view(np.uint32) != np.ascontiguousarray(final_dev).view(np.uint32)).reshape(len(host), -1).any(axis=1))[0]
-    for i in bad.tolist():
-        d2, m2, c2 = ctx.warp_batch(device_frames[i:i + 1], host[i:i + 1], plan.output_size, interp="bilinear",
-                                    border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
-        dst[i].copy_(d2[0])
-        mask[i].copy_(m2[0])
-        counts[i].copy_(c2[0])
+    # runs of consecutive frames go in one launch each, straight into their slices of the outputs: the one situation with
+    # MANY differing frames (an exactly constant rotation path after a sticky fallback) costs one more warp of those
+    # frames, not a launch per frame
+    if bad.size:
+        cuts = np.nonzero(np.diff(bad) > 1)[0] + 1
+        for run in np.split(bad, cuts):
+            a, b = int(run[0]), int(run[-1]) + 1
+            _, _, c2 = ctx.warp_batch(device_frames[a:b], host[a:b], plan.output_size, interp="bilinear",
+                                      border=hm.border_value(padding_rgb), want_mask=True, want_count=True, out=dst[a:b],
+                                      out_mask=mask[a:b])
+            counts[a:b].copy_(c2)
     return int(bad.size)
 
 

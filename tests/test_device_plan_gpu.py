@@ -225,3 +225,28 @@ def test_plan_kernel_reads_a_gathered_table_as_the_all_gather_leaves_it(ctx, pkg
             assert np.array_equal(a.view(np.uint64 if a.dtype == np.float64 else np.uint32), b.view(np.uint64 if b.dtype == np.float64 else np.uint32)), world
     with pytest.raises(native.VstabError, match="segments hold"):
         ctx.flow_plan_device(dev.data_ptr(), pairs, *args, seg_pairs=[3, 4], seg_rows=4)
+
+
+def test_many_wrong_frames_are_rewarped_in_runs(ctx, pkg, monkeypatch):
+    """_rewarp_mismatched with several runs of differing frames (a forged device-plan result: frames 2-4, 7 and 10-11 marked
+    wrong): the runs are warped again in place, everything else is left alone, the count is returned."""
+    import torch
+
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import host_math as hm
+
+    frames = _clip(ctx, 12, 640, 360, "similarity", amp=1.5)
+    want, _ = _run(ctx, frames, "similarity", monkeypatch, device_plan=False)
+    final = np.array([e["applied_matrix"] for e in want.meta["stabilization_warp"]["per_frame"]], np.float32)
+    plan = fp.FlowPlan(final, (640, 360), {}, {}, {}, "crop_and_pad", (640, 360), 16.0)
+    forged = final.copy()
+    wrong = [2, 3, 4, 7, 10, 11]
+    forged[wrong, 0, 2] += 1.0
+    dst = want.frames.clone()
+    mask = want.masks[..., 0].clone().contiguous()
+    counts = torch.zeros(12, dtype=torch.int32, device=ctx.device)
+    dst[wrong] = -1.0                                            # what a wrong plan would have left there
+    n = fp._rewarp_mismatched(ctx, frames, plan, forged, dst, mask, counts, (127, 127, 127))
+    assert n == 6 and bool((dst == want.frames).all()) and bool((mask == want.masks[..., 0]).all())
+    untouched = [i for i in range(12) if i not in wrong]
+    assert bool((counts[untouched] == 0).all())
