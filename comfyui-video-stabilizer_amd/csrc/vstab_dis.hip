@@ -1297,7 +1297,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     // ---- workspace layout (two passes: size, then carve) ----
     uint8_t* I[MAX_LEVELS]; uint8_t* Iext[MAX_LEVELS]; short* Ixs[MAX_LEVELS]; short* Iys[MAX_LEVELS];
     float* tensor[MAX_LEVELS]; float* Ul[MAX_LEVELS]; float* Vl[MAX_LEVELS];
-    float *aux = nullptr, *Sx = nullptr, *Sy = nullptr;
+    float *aux = nullptr, *aux_c = nullptr, *Sx = nullptr, *Sy = nullptr;
     VrBufs vb{};
     const LevelGeom& F = G[FINEST];
     const size_t npF = (size_t)P * F.h * F.w;
@@ -1313,6 +1313,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             Vl[i] = c.take<float>((size_t)P * G[i].h * G[i].w);
         }
         aux = c.take<float>(5 * (size_t)n * F.h * F.ws);
+        aux_c = c.take<float>(5 * (size_t)n * G[coarsest].h * G[coarsest].ws);   // the coarsest level's own (it is prepared on the main stream)
         Sx = c.take<float>((size_t)P * F.hs * F.ws);
         Sy = c.take<float>((size_t)P * F.hs * F.ws);
         vb.avg = c.take<float>(npF); vb.Iz = c.take<float>(npF);
@@ -1355,12 +1356,18 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     }
     for (int i = coarsest; i >= FINEST; i--) {
         const LevelGeom& g = G[i];
-        hipLaunchKernelGGL(pad_replicate_kernel, frame_grid((long long)(g.h + 32) * (g.w + 32), n), dim3(256), 0, ps, I[i], Iext[i], n, g.h, g.w);
-        hipLaunchKernelGGL(sobel_kernel, frame_grid((long long)g.h * g.w, n), dim3(256), 0, ps, I[i], Ixs[i], Iys[i], n, g.h, g.w);
-        hipLaunchKernelGGL(tensor_h_kernel, frame_grid((long long)g.h * g.ws, n), dim3(256), 0, ps, Ixs[i], Iys[i], aux, n, g.h, g.w, g.ws);
-        hipLaunchKernelGGL(tensor_v_kernel, dim3((unsigned)((g.ws + 63) / 64), (unsigned)n, 5u), dim3(64), 0, ps, aux, tensor[i], n, g.h, g.ws, g.hs);
+        // the coarsest level is needed at once: it is prepared on the main stream, behind the pyramid, so that the chain's
+        // first patch search does not wait for a cross-stream event (its own scratch: the other levels' `aux` is in use on
+        // the second stream at the same time)
+        const bool own = i == coarsest;
+        hipStream_t s_i = own ? st : ps;
+        float* aux_i = own ? aux_c : aux;
+        hipLaunchKernelGGL(pad_replicate_kernel, frame_grid((long long)(g.h + 32) * (g.w + 32), n), dim3(256), 0, s_i, I[i], Iext[i], n, g.h, g.w);
+        hipLaunchKernelGGL(sobel_kernel, frame_grid((long long)g.h * g.w, n), dim3(256), 0, s_i, I[i], Ixs[i], Iys[i], n, g.h, g.w);
+        hipLaunchKernelGGL(tensor_h_kernel, frame_grid((long long)g.h * g.ws, n), dim3(256), 0, s_i, Ixs[i], Iys[i], aux_i, n, g.h, g.w, g.ws);
+        hipLaunchKernelGGL(tensor_v_kernel, dim3((unsigned)((g.ws + 63) / 64), (unsigned)n, 5u), dim3(64), 0, s_i, aux_i, tensor[i], n, g.h, g.ws, g.hs);
         VSTAB_HIP(hipGetLastError());
-        if (two_streams) VSTAB_HIP(hipEventRecord(ctx->ev_prep[i], ps));
+        if (two_streams && !own) VSTAB_HIP(hipEventRecord(ctx->ev_prep[i], ps));
     }
     VSTAB_HIP(hipMemsetAsync(Ul[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
     VSTAB_HIP(hipMemsetAsync(Vl[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
@@ -1378,7 +1385,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.spin_limit = 1 << 22;
         if (const char* e = getenv("VSTAB_DEBUG_PIS_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // tests: 0 forces the timeout report
         pa.status = ctx->d_status;
-        if (two_streams) VSTAB_HIP(hipStreamWaitEvent(st, ctx->ev_prep[i], 0));   // this level's padded image, gradients, tensor
+        if (two_streams && i != coarsest) VSTAB_HIP(hipStreamWaitEvent(st, ctx->ev_prep[i], 0));   // this level's padded image, gradients, tensor
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
         // one wavefront per stripe walks its rows in groups of four; two share the groups where a stripe has more rows
