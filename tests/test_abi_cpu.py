@@ -491,3 +491,23 @@ def test_clip_bounding_boxes_equal_numpy(pkg):
             item_mins, item_maxs = hm._compute_bounding_boxes(list(mats[:300]), w, h)
             assert np.array_equal(mins[:300], item_mins, equal_nan=True) and np.array_equal(maxs[:300], item_maxs, equal_nan=True)
     assert native.bounding_boxes(np.zeros((0, 3, 3), np.float32), 10, 10)[0].shape == (0, 2)
+
+
+def test_roofline_traffic_is_tied_to_the_warp_sources(tmp_path, monkeypatch):
+    """bench.warp_traffic_record: the PMC traffic figure is handed out only for the workload and the kernel sources it was
+    collected on (sha256 of csrc/vstab_warp.hip + vstab_internal.h in profiles/warp_traffic.json); otherwise None + reason."""
+    import json
+
+    import bench
+
+    rec = json.loads((ROOT / "profiles" / "warp_traffic.json").read_text())
+    traffic, why = bench.warp_traffic_record(256, 1920, 1080)
+    if rec["kernel_source_sha256"] == bench.warp_source_sha256():
+        assert traffic == rec["hbm_bytes_per_launch"] and rec["kernel_source_sha256"][:12] in why
+        assert 0.99 < traffic / rec["algorithmic_bytes_per_launch"] < 1.01
+    else:   # the warp sources were edited after the collection: the bench line must say so, not quote the stale figure
+        assert traffic is None and "re-run tools/pmc_traffic.sh" in why
+    assert bench.warp_traffic_record(128, 1920, 1080)[0] is None
+    monkeypatch.setattr(bench, "warp_source_sha256", lambda: "0" * 64)
+    traffic, why = bench.warp_traffic_record(256, 1920, 1080)
+    assert traffic is None and "other warp kernel sources" in why
