@@ -301,6 +301,9 @@ def test_c4_sized_clip_two_ranks_equal_single_process(pkg, ctx, tmp_path):
     frames = bench.synth_clip(total, 0, h, w, torch.device("cuda", 0))
     res = fp._stabilize_frames(hm._normalize_video_input(frames), *bench.FLOW_ARGS, ctx=ctx, keep_on_device=True)
     del frames
+    # the single-process side ran on the device-formed plan (the two ranks above form theirs on the host) and none of the
+    # 1024 device matrices differed from the host's: the equality below is the speculation holding, not its fallback
+    assert fp.LAST_DEVICE_PLAN == {"used": True, "mismatched_frames": 0}
     want_dst, want_mask = _frame_checksums(res.frames), _frame_checksums(res.masks)
     parts = [torch.load(tmp_path / f"c4_{r}.pt") for r in range(2)]
     assert [p["start"] for p in parts] == [0, 512]
