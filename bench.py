@@ -9,15 +9,19 @@ outputs left in HBM, entered at the node boundary (`_normalize_video_input` on t
     [all-gather of fit records if N > 1] -> trajectory -> framing -> warp + mask + padding counts -> meta.
 
 Workloads (BASELINE.json configs):
-  N = 1  C2: 256 synthetic 1080p frames, Flow similarity + crop_and_pad, defaults.
-  N > 1  C4: ONE 1024-frame 1080p clip sharded contiguously over the N ranks (1-frame halo, RCCL all-gather of the
-         fit records): total work fixed -> "scaling": "strong".  `--total-frames T` picks another clip length (also at
-         N = 1: `--gpus 1 --total-frames 1024` is the same clip on one GPU), `--frames F` fixes the frames per GPU
-         instead ("weak").
+  N = 1  C2: 256 synthetic 1080p frames, Flow similarity + crop_and_pad, defaults (the configuration the metric is quoted on).
+  N > 1  the same 256 frames of work on every GPU: ONE 256 x N-frame 1080p clip sharded contiguously over the N ranks
+         (1-frame halo, RCCL all-gather of the fit records, the plan over the whole clip on every rank): per-GPU work
+         fixed -> "scaling": "weak".  `--total-frames T` fixes the clip instead ("strong"; also at N = 1:
+         `--gpus 1 --total-frames 1024` is the C4 clip on one GPU), `--frames F` picks another per-GPU share.
+         The default N > 1 line also carries, measured after the timed loop on the same ranks:
+           `c4`  BASELINE configs[3]: one 1024-frame clip over the N ranks, total work fixed ("strong"), with the one-GPU
+                 time of the same clip next to it (static record under profiles/);
+           `c5`  BASELINE configs[4] (below).
   --workload c5   BASELINE configs[4] as the timed step: one 512-frame 4K clip (64 frames = one GPU's share at N = 1), Flow
          expand -> Motion Apply (expand, bilinear, motion_blur 0.5, Ultra = 33 samples) on the original frames, sharded
-         like C4 (the replay half has no collective).  At N > 1 the default run carries the same measurement as a
-         `c5` object on the C4 line (outside the timed loop), so a multi-GPU driver run reports both configs.
+         the same way (the replay half has no collective).
+  --workload c3   BASELINE configs[2] as the timed step (256 x 1080p, Flow perspective -> Motion Apply bicubic, 0.5, High).
 N > 1 needs one process per GPU.  Started under torchrun (WORLD_SIZE set) this file is a rank; started plainly with
 --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before
 anything touches the GPU and relays its output (never an exec).
@@ -35,7 +39,7 @@ Also on the JSON line (rank 0):
   parity_at_size (N = 1, inside the cpu_baseline leg: the oracle is the checker) the HIP run against the oracle's run of the
                  same 256 frames: matrices, confidences, every output pixel, every mask pixel, padding statistics
   batch_invariance (N = 1) pairs {0,127,254} re-run as 2-frame clips and frames {0,127,255} warped alone == the clip run
-  c5             (N > 1, or --force-dist) BASELINE configs[4] on the same ranks, outside the timed loop
+  c4, c5         (N > 1; c5 also with --force-dist) BASELINE configs[3] / configs[4] on the same ranks, outside the timed loop
   host_roundtrip the node as ComfyUI calls it: CPU tensor in -> CPU tensors out (PCIe-inclusive; never `value`)
   motion_apply   Motion Apply rates for C3 (1080p, bicubic, blur 0.5, S=17) and C5's per-GPU share (4K, bilinear,
                  blur 0.5, S=33), device-resident (N = 1 only; measured outside the timed loop)
@@ -626,12 +630,12 @@ def main() -> int:
     ap_.add_argument("--gpus", type=int, default=1)
     ap_.add_argument("--steps", type=int, default=5)
     ap_.add_argument("--warmup", type=int, default=2)
-    ap_.add_argument("--frames", type=int, default=None, help="frames per GPU (weak scaling); default: C2 = 256 at N=1")
-    ap_.add_argument("--total-frames", type=int, default=None, help="clip length sharded over all GPUs (strong scaling); default at N>1: C4 = 1024")
+    ap_.add_argument("--frames", type=int, default=None, help="frames per GPU (weak scaling); default: 256 (C2 at N=1; one 256 x N-frame clip over N GPUs)")
+    ap_.add_argument("--total-frames", type=int, default=None, help="clip length sharded over all GPUs (strong scaling), e.g. 1024 = C4 as the line's value")
     ap_.add_argument("--height", type=int, default=None, help="default 1080 (2160 for --workload c5)")
     ap_.add_argument("--width", type=int, default=None, help="default 1920 (3840 for --workload c5)")
     ap_.add_argument("--workload", choices=("auto", "c5", "c3"), default="auto",
-                     help="auto: C2 at N=1 / C4 at N>1 (the headline metric; at N>1 a C5 object rides on the same line). "
+                     help="auto: the headline metric -- C2 at N=1, a C2-sized shard per GPU at N>1 (weak scaling; C4 and C5 objects ride on the same line). "
                           "c5: time BASELINE configs[4] (512 x 4K Flow expand -> Motion Apply blur Ultra) as the line's value. "
                           "c3: time BASELINE configs[2] (256 x 1080p Flow perspective -> Motion Apply bicubic, blur 0.5, High)")
     ap_.add_argument("--c5-frames", type=int, default=None, help="clip length of the C5 workload (default: 512 over N > 1 GPUs; 64 = one GPU's share of the 8-GPU config at N = 1)")
@@ -722,55 +726,81 @@ def main() -> int:
     elif world == 1:
         total, scaling, label = 256, "weak", "C2: 256-frame clip"
     else:
-        total, scaling, label = 1024, "strong", "C4: one 1024-frame clip"
-    start, end = vd.shard_range(total, world, rank)
-    n_local = end - start
-    halo = 1 if (rank > 0 and n_local > 0) else 0
-    frames = synth_clip(n_local + halo, start - halo, h, w, device)
-    torch.cuda.synchronize()
-    stats: dict = {}
+        # the metric's own workload on every GPU (BASELINE configs[1]: 256 x 1080p per GPU), as ONE clip of 256 x N frames
+        # sharded over the ranks: per-GPU work fixed as N grows.  BASELINE configs[3] (C4: one 1024-frame clip, total work
+        # fixed) is timed after it and rides on the same line as the `c4` object.
+        total, scaling, label = 256 * world, "weak", f"C2-sized shard per GPU: one {256 * world}-frame clip"
 
-    def step():
-        if not use_dist:
-            context = hm._normalize_video_input(frames)   # F0 at the node boundary (the range sniff rides on the gray pass)
-            res = fp._stabilize_frames(context, *FLOW_ARGS, ctx=ctx, keep_on_device=True)
-            return res.frames, res.masks, res.meta
-        return vd.stabilize_sharded(ctx, frames, total, *FLOW_ARGS, stats=stats, want_meta=(rank == 0))
-
-    def fence():
-        if use_dist:
-            dist.barrier()
+    def time_flow(total_frames: int, steps: int, warmup: int) -> dict:
+        """warmup + `steps` timed Flow steps on this rank's shard of one `total_frames`-frame clip, between fences;
+        max over ranks.  The shard's frames stay allocated in the result (the one-GPU extras re-use them)."""
+        start, end = vd.shard_range(total_frames, world, rank)
+        n_local = end - start
+        halo = 1 if (rank > 0 and n_local > 0) else 0
+        frames = synth_clip(n_local + halo, start - halo, h, w, device)
         torch.cuda.synchronize()
+        stats: dict = {}
 
-    for _ in range(args.warmup):
-        out = step()
-        del out
-    fence()
-    ctx.set_timing(True)   # clears the per-kind totals: only the timed steps below are counted
-    stats.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        meta = out[2]
-        del out
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step():
+            if not use_dist:
+                context = hm._normalize_video_input(frames)   # F0 at the node boundary (the range sniff rides on the gray pass)
+                res = fp._stabilize_frames(context, *FLOW_ARGS, ctx=ctx, keep_on_device=True)
+                return res.frames, res.masks, res.meta
+            return vd.stabilize_sharded(ctx, frames, total_frames, *FLOW_ARGS, stats=stats, want_meta=(rank == 0))
 
-    rc = 0
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total * args.steps / elapsed
-        out_w, out_h = meta["stabilization_warp"]["output_size"]
+        def fence():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            out = step()
+            del out
+        fence()
+        ctx.set_timing(True)   # clears the per-kind totals: only the timed steps below are counted
+        stats.clear()
+        meta = None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+            meta = out[2]
+            del out
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         # HIP events recorded by the library on the launch stream around every call; summed without host
         # synchronisation inside the timed loop, read here after the closing fence
         stage_ms = {}
         for kind in ("gray", "dis", "fit", "warp"):
             total_ms, launches = ctx.kernel_ms_stats(kind)
             stage_ms[kind] = total_ms / max(launches, 1)
+        return {"elapsed": elapsed, "n_local": n_local, "frames": frames, "meta": meta, "step": step, "stage_ms": stage_ms,
+                "host_ms": {k: round(v / steps, 3) for k, v in stats.items()}}
+
+    def same_clip_on_one_gpu(total_frames: int):
+        """the denominator of a strong-scaling ratio is the SAME clip on one GPU, not the N=1 default (C2, 256 frames)"""
+        refs = sorted((ROOT / "profiles").glob("r*_c4_single_gpu.json"))
+        if not refs:
+            return None
+        rj = json.loads(refs[-1].read_text())
+        if rj.get("total_frames") != total_frames or rj.get("size") != [w, h]:
+            return None
+        return {"frames_per_s": rj["frames_per_s"], "ms_per_step": rj["ms_per_step"],
+                "source": f"profiles/{refs[-1].name} (static: `bench.py --gpus 1 --total-frames {total_frames}` on one MI355X, "
+                          "not measured in this run)"}
+
+    run = time_flow(total, args.steps, args.warmup)
+    elapsed, n_local, frames, meta, step, stage_ms = (run[k] for k in ("elapsed", "n_local", "frames", "meta", "step", "stage_ms"))
+    del run["frames"], run["step"]   # `frames` and `step` (whose closure holds the clip) are the only references left
+
+    rc = 0
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total * args.steps / elapsed
+        out_w, out_h = meta["stabilization_warp"]["output_size"]
         warp_avg_ms = stage_ms["warp"]
         launch_bytes = WARP_BYTES_PER_PIXEL * out_w * out_h * n_local
         achieved = launch_bytes / (warp_avg_ms * 1e-3) / 1e9
@@ -783,18 +813,12 @@ def main() -> int:
             "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo, RCCL all-gather of fit records",
             "stage_ms": {k: round(float(v), 3) for k, v in stage_ms.items()},
         }
-        ref = ROOT / "profiles" / "r03_c4_single_gpu.json"
-        if world > 1 and scaling == "strong" and ref.exists():
-            rj = json.loads(ref.read_text())
-            if rj.get("total_frames") == total and rj.get("size") == [w, h]:
-                # the denominator of a strong-scaling ratio is the SAME clip on one GPU, not the N=1 default (C2, 256 frames)
-                config["same_clip_on_one_gpu"] = {"frames_per_s": rj["frames_per_s"], "ms_per_step": rj["ms_per_step"],
-                                                  "source": "profiles/r03_c4_single_gpu.json (static: `bench.py --gpus 1 --total-frames "
-                                                            f"{total}` on one MI355X, not measured in this run)"}
+        if world > 1 and scaling == "strong" and same_clip_on_one_gpu(total) is not None:
+            config["same_clip_on_one_gpu"] = same_clip_on_one_gpu(total)
         if args.rehearse_on_one_gpu:
             config["rehearsal"] = "all ranks share cuda:0, gloo control plane: a code-path rehearsal, NOT a multi-GPU measurement"
         if use_dist:
-            config["rank0_host_ms"] = {k: round(v / args.steps, 3) for k, v in stats.items()}
+            config["rank0_host_ms"] = run["host_ms"]
             config["rank0_host_ms_note"] = ("host wall-clock per phase of rank 0's step; gather_fits + gather_counts = the two "
                                             "collectives, plan + meta = replicated host work (meta on rank 0 only)")
         line = {
@@ -873,23 +897,38 @@ def main() -> int:
                     host = frames.cpu()
                     line["host_roundtrip"] = measure_host_roundtrip(nodes, host)
                     del host
-                    del frames
+                    del frames, step
                     torch.cuda.empty_cache()
                     line["motion_apply"] = measure_motion_apply(ctx, torch, device, check=checks and args.cpu_frames >= 2)
                 except Exception as exc:  # the headline line must survive a failure of the extras
                     line["extras_error"] = f"{type(exc).__name__}: {exc}"
-    c5 = None
+    c4 = c5 = None
     if use_dist and not args.no_extras:
-        # BASELINE configs[4] on the same ranks, outside the timed loop above (every rank takes part: it has collectives).
-        # `--gpus 1 --force-dist` rehearses exactly this path on one GPU's share of the clip.
-        del frames
+        # BASELINE configs[3] and configs[4] on the same ranks, outside the timed loop above (every rank takes part: both
+        # have collectives).  `--gpus 1 --force-dist` rehearses exactly this path on one GPU's share of the clips.
+        del frames, step
         torch.cuda.empty_cache()
+        if world > 1 and args.frames is None and args.total_frames is None:
+            try:
+                c4_run = time_flow(1024, args.steps, max(1, args.warmup))
+                c4 = {"workload": f"C4: one 1024-frame clip, {w}x{h}, Flow similarity + crop_and_pad, sharded over {world} GPUs "
+                                  "(BASELINE configs[3]; total work fixed)",
+                      "scaling": "strong", "value": round(1024 * args.steps / c4_run["elapsed"], 2), "unit": "frames/s",
+                      "ms_per_step": round(c4_run["elapsed"] / args.steps * 1e3, 3), "steps": args.steps,
+                      "frames_per_gpu": c4_run["n_local"], "stage_ms": {k: round(float(v), 3) for k, v in c4_run["stage_ms"].items()},
+                      "rank0_host_ms": c4_run["host_ms"], "same_clip_on_one_gpu": same_clip_on_one_gpu(1024)}
+                del c4_run
+            except Exception as exc:   # every rank reaches the same collectives or none: a failure here is the same on all ranks
+                c4 = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
         try:
             c5 = run_c5(ctx, torch, dist, device, rank, world, True, args.c5_frames or (512 if world > 1 else 64), 2160, 3840,
                         max(2, args.steps // 2), 1)
         except Exception as exc:   # run_c5 agrees on allocation and on its first pass across the ranks before it times anything
             c5 = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
+        if c4 is not None:
+            line["c4"] = c4
         if c5 is not None:
             line["c5"] = c5
         print(json.dumps(line), flush=True)
