@@ -4,6 +4,7 @@ halo-split clip; outputs and meta must equal the single-process result bit for b
 import json
 import os
 import socket
+import subprocess
 import sys
 from pathlib import Path
 
@@ -314,3 +315,26 @@ def test_c4_sized_clip_two_ranks_equal_single_process(pkg, ctx, tmp_path):
             assert torch.equal(f, res.frames[i].cpu()), i
     assert json.loads((tmp_path / "c4_meta.json").read_text()) == json.loads(json.dumps(res.meta))
     assert res.meta["frames"] == total and len(res.meta["estimated_motion"]["per_transition"]) == total - 1
+
+
+def test_bench_default_multi_rank_line_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2` as the driver's scaling run starts it, except that both ranks share this box's GPU (gloo control plane,
+    `--rehearse-on-one-gpu`): the child launcher, the default workload (the metric's 256 frames per GPU as one 512-frame clip, weak
+    scaling), the `c4` object (BASELINE configs[3], strong scaling, with the same clip's one-GPU record) and the `c5` object all
+    have to produce their part of the ONE JSON line.  The numbers mean nothing here; the structure is what a multi-GPU run prints."""
+    root = ROOT
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1", "--warmup", "1",
+                           "--c5-frames", "4"], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["metric"] == "stabilized frames/sec (1080p, similarity mode)"
+    assert line["config"]["total_frames"] == 512 and line["config"]["frames_per_gpu"] == 256 and "rehearsal" in line["config"]
+    assert line["value"] > 0 and abs(line["value"] - 512 / (line["ms_per_step"] * 1e-3)) <= 0.01 * line["value"]
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 28 * 1920 * 1080 * 256 and "cpu_baseline" not in line
+    c4 = line["c4"]
+    assert "error" not in c4 and c4["scaling"] == "strong" and c4["frames_per_gpu"] == 512 and c4["value"] > 0
+    assert c4["same_clip_on_one_gpu"]["ms_per_step"] > 0 and "rank0_host_ms" in c4
+    c5 = line["c5"]
+    assert "error" not in c5 and c5["total_frames"] == 4 and c5["n_gpus"] == 2 and c5["value"] > 0
