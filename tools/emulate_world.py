@@ -18,6 +18,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8);
 ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--device-plan", type=int, default=1, help="1: the round-4 flow (plan formed on the device behind the gathered table, "
                 "host plan + verification while the warp runs); 0: the host-plan flow of rounds 1-3")
+ap.add_argument("--gc", choices=("default", "freeze", "off"), default="default",
+                help="host-runtime experiment: gc.freeze() after the warm-up steps / the cyclic collector off during the timed steps")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 ctx = native.Context(0)
@@ -96,6 +98,11 @@ tm = []
 for _ in range(3):
     step(tm)
 torch.cuda.synchronize()
+import gc
+if args.gc == "freeze":
+    gc.collect(); gc.freeze()
+elif args.gc == "off":
+    gc.collect(); gc.disable()
 tm = []
 t0 = time.perf_counter()
 for _ in range(args.steps):
