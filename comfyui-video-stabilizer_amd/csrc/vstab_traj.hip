@@ -152,11 +152,23 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     }
     __syncthreads();
     // ---- path = prefix sum of the deltas (flow.py:356-358), one lane per parameter, in order
+    //      The additions stay sequential (np.cumsum's order); a batch of deltas is read from LDS before its chain of adds
+    //      starts -- element by element the loop pays an LDS round trip per frame (~80 cycles: 70 us of a 2048-frame plan).
     if ((int)threadIdx.x < p) {
         const int c = threadIdx.x;
+        constexpr int B = 16;
         double acc = 0.0;
-#pragma unroll 8
-        for (int i = 1; i < frames; i++) {
+        int i = 1;
+        for (; i + B <= frames; i += B) {
+            double v[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) v[k] = s_path[(i + k) * p + c];
+#pragma unroll
+            for (int k = 0; k < B; k++) { acc = acc + v[k]; v[k] = acc; }
+#pragma unroll
+            for (int k = 0; k < B; k++) s_path[(i + k) * p + c] = v[k];
+        }
+        for (; i < frames; i++) {
             acc = acc + s_path[i * p + c];
             s_path[i * p + c] = acc;
         }
