@@ -100,6 +100,15 @@ extern "C" {
 
 int vstab_abi_version(void) { return VSTAB_ABI_VERSION; }
 
+int vstab_test_hooks(void)
+{
+#ifdef VSTAB_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char* vstab_last_error(void) { return g_err; }
 
 int vstab_create(vstab_ctx** out, int device)
@@ -180,6 +189,7 @@ int vstab_set_timing(vstab_ctx* ctx, int enabled)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_set_timing: ctx is NULL");
     ctx->timing = enabled != 0;
+    ctx->timing_detail = enabled >= 2;
     for (auto& kv : ctx->timers) { kv.second.pending = false; kv.second.total_ms = 0.0; kv.second.launches = 0; }
     return 0;
 }

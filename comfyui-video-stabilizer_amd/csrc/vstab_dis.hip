@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
+#include <memory>
 
 namespace {
 
@@ -345,7 +346,7 @@ struct PisArgs {
     float* Sx;             // [P][hs][ws]
     float* Sy;
     int n, w, h, ws, hs, stripe_sz;
-    int spin_limit;        // a wavefront's total spin allowance over its LDS progress-counter waits (VSTAB_DEBUG_PIS_SPIN_LIMIT overrides it in tests)
+    int spin_limit;        // a wavefront's total spin allowance over its LDS progress-counter waits (the test build's VSTAB_DEBUG_PIS_SPIN_LIMIT overrides it)
     int* status;           // host-mapped status word of the context (vstab_internal.h): a timed-out wait is reported there
 };
 
@@ -1344,6 +1345,8 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         }
         ps = ctx->prep_stream;
     }
+    // (set_timing level 2 only: events around the stages of this call, vstab_internal.h)
+    auto prep_timer = std::make_unique<DetailTimer>(ctx, "dis_prep");
     for (int i = FINEST; i <= coarsest; i++) {
         const LevelGeom& g = G[i];
         if (i == FINEST) { if (launch_area(st, gray, I[i], n, h, w, g.h, g.w)) return 1; }
@@ -1372,6 +1375,8 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     VSTAB_HIP(hipMemsetAsync(Ul[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
     VSTAB_HIP(hipMemsetAsync(Vl[coarsest], 0, sizeof(float) * (size_t)P * G[coarsest].h * G[coarsest].w, st));
 
+    prep_timer.reset();
+
     const float zeta = 0.1f, epsilon = 0.001f, alpha = 20.0f, delta = 5.0f, gamma = 10.0f, omega = 1.6f;
     const float zeta2 = zeta * zeta, eps2 = epsilon * epsilon, gamma2 = gamma / 2, delta2 = delta / 2, alpha2 = alpha / 4;
 
@@ -1383,11 +1388,17 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         pa.n = n; pa.w = g.w; pa.h = g.h; pa.ws = g.ws; pa.hs = g.hs;
         pa.stripe_sz = (int)std::ceil(g.hs / 8.0);
         pa.spin_limit = 1 << 22;
-        if (const char* e = getenv("VSTAB_DEBUG_PIS_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // tests: 0 forces the timeout report
+#ifdef VSTAB_TEST_HOOKS   // fault injector of the test build (lib/libvstab_hooks.so): 0 forces the timeout report
+        if (const char* e = getenv("VSTAB_DEBUG_PIS_SPIN_LIMIT")) pa.spin_limit = atoi(e);
+#endif
         pa.status = ctx->d_status;
         if (two_streams && i != coarsest) VSTAB_HIP(hipStreamWaitEvent(st, ctx->ev_prep[i], 0));   // this level's padded image, gradients, tensor
         const size_t lds_bytes = (((size_t)(g.w + 32) * (g.h + 32) + 15) & ~size_t(15)) + sizeof(float) * 2 * (size_t)g.hs * g.ws + sizeof(int) * 2 * (size_t)g.hs;
         VSTAB_REQUIRE(lds_bytes <= 160 * 1024, "vstab_dis_flow_batch: level %dx%d needs %zu B of LDS (> 160 KB)", g.w, g.h, lds_bytes);
+        char kind_pis[24], kind_level[24];
+        snprintf(kind_pis, sizeof(kind_pis), "dis_pis4_L%d", i);
+        snprintf(kind_level, sizeof(kind_level), "dis_level_L%d", i);
+        auto stage_timer = std::make_unique<DetailTimer>(ctx, kind_pis);
         // one wavefront per stripe walks its rows in groups of four; two share the groups where a stripe has more rows
         if (pa.stripe_sz > 4) {
             if (lds_bytes > 64 * 1024)
@@ -1398,6 +1409,8 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pis4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL(pis4_kernel<1>, dim3((unsigned)P * 2), dim3(64 * PIS_STRIPES_PER_BLOCK), lds_bytes, st, pa);
         }
+        stage_timer.reset();
+        stage_timer = std::make_unique<DetailTimer>(ctx, kind_level);
         LevelArgs la{};
 #ifdef VSTAB_FUSED_TRACE
         la.dbg = g_dis_dbg ? g_dis_dbg + 16 * i : nullptr;
@@ -1461,7 +1474,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             }
         }
         VSTAB_HIP(hipGetLastError());
+        stage_timer.reset();
     }
+    DetailTimer final_timer(ctx, "dis_final");
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);
     const float mul = (float)(1 << FINEST);
     if (grid_flow) {

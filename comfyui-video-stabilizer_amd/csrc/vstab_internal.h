@@ -51,6 +51,7 @@ struct vstab_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    bool timing_detail = false;                 // vstab_set_timing(ctx, 2): also events around the stages INSIDE a DIS call
     bool dis_first_pair_is_clip_start = true;   // see vstab_dis_set_clip_start
     std::map<std::string, EventPair> timers;
     // staging for small per-call parameter tables (pinned host + device mirror)
@@ -105,6 +106,27 @@ struct KernelTimer {
         }
     }
     ~KernelTimer() {
+        if (ev) {
+            (void)hipEventRecord(ev->stop, ctx->stream);
+            ev->pending = true;
+        }
+    }
+};
+
+// The same around one stage inside a call, only under vstab_set_timing(ctx, 2): the events sit between dependent kernels,
+// where they lengthen the chain a little, and a kind used twice in one call folds (waits for) its previous measurement --
+// for a measurement pass of its own, never inside a timed loop.
+struct DetailTimer {
+    vstab_ctx* ctx;
+    EventPair* ev = nullptr;
+    DetailTimer(vstab_ctx* c, const char* k) : ctx(c) {
+        if (ctx->timing && ctx->timing_detail) {
+            ev = vstab_timer_slot(ctx, k);
+            if (ev && ev->pending) (void)vstab_timer_fold(ev);
+            if (ev) (void)hipEventRecord(ev->start, ctx->stream);
+        }
+    }
+    ~DetailTimer() {
         if (ev) {
             (void)hipEventRecord(ev->stop, ctx->stream);
             ev->pending = true;

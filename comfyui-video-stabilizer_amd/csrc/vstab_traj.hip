@@ -363,7 +363,9 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     a.target = reinterpret_cast<double*>(base + L.target);
     a.region = reinterpret_cast<double*>(base + L.region);
     a.perturb = -1;
+#ifdef VSTAB_TEST_HOOKS   // fault injector of the test build (lib/libvstab_hooks.so); the shipped library reads no such variable
     if (const char* e = getenv("VSTAB_DEBUG_PLAN_PERTURB")) a.perturb = atoi(e);
+#endif
     if (lds > 64 * 1024)
         VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_T), lds, ctx->stream, a);

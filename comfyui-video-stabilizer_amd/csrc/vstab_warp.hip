@@ -796,14 +796,27 @@ int launch_blur(WarpArgs a, bool with_mask, hipStream_t st)
     // of milliseconds)
     if (const char* e = getenv("VSTAB_BLUR_FAST")) a.blur_fast = a.blur_fast && atoi(e) != 0;
     // The staged window needs more than the default 64 KB of dynamic LDS for bicubic (76.5 KB): asked for ONCE per kernel
-    // instance; a device (or runtime) that refuses it gets the general loop everywhere with the small allocation instead of
-    // an error -- the staged path is an optimisation, the general loop is the definition.
-    static const bool big_lds_mask = G::LDS_BYTES <= 64 * 1024 ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
-    static const bool big_lds_plain = G::LDS_BYTES <= 64 * 1024 ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess;
+    // instance AND DEVICE (hipFuncSetAttribute applies to the current device's function object, and one process may hold a
+    // context per GPU); a device (or runtime) that refuses it gets the general loop everywhere with the small allocation
+    // instead of an error -- the staged path is an optimisation, the general loop is the definition.
+    constexpr int MAX_DEV = 64;
+    static signed char opt_in[2][MAX_DEV] = {};   // [with_mask][device]: 0 not asked yet, 1 granted, -1 refused
+    int dev = 0;
+    VSTAB_HIP(hipGetDevice(&dev));
+    bool big_lds = G::LDS_BYTES <= 64 * 1024;
+    if (!big_lds) {
+        signed char* slot = (dev >= 0 && dev < MAX_DEV) ? &opt_in[with_mask ? 1 : 0][dev] : nullptr;
+        signed char state = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
+        if (state == 0) {
+            const void* fn = with_mask ? reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, true>)
+                                       : reinterpret_cast<const void*>(warp_blur_kernel<INTERP, SUBPIX, false>);
+            state = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) == hipSuccess ? 1 : -1;
+            if (slot) __atomic_store_n(slot, state, __ATOMIC_RELAXED);
+        }
+        big_lds = state > 0;
+    }
     size_t lds = G::LDS_BYTES;
-    if (!(with_mask ? big_lds_mask : big_lds_plain)) {
+    if (!big_lds) {
         (void)hipGetLastError();
         a.blur_fast = 0;
         lds = sizeof(float) * 32 * 4;

@@ -69,9 +69,12 @@ struct Team {
     template <class Body>
     void run(int want, Body body)
     {
-        // test knob: pretend the box refuses every helper after the first k (k >= 0)
+#ifdef VSTAB_TEST_HOOKS   // fault injector of the test build: pretend the box refuses every helper after the first k (k >= 0)
         const char* e = getenv("VSTAB_DEBUG_XFER_SPAWN_FAIL");
         const int refuse_after = e ? atoi(e) : -1;
+#else
+        const int refuse_after = -1;
+#endif
         try {
             for (int t = 1; t < want; t++) {
                 if (refuse_after >= 0 && t > refuse_after) throw std::system_error(EAGAIN, std::generic_category());

@@ -450,16 +450,18 @@ def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
 # device's bit for bit: a frame whose matrix differs (the device's atan2 / log / exp / cos / sin may differ from glibc's in
 # the last bit of a double, which survives the float32 cast about once in 1e8 entries) is warped again with the host's.
 # What is returned is therefore always the host plan's result.  VSTAB_DEVICE_PLAN=0 switches the speculation off (A/B).
-LAST_DEVICE_PLAN: Dict[str, Any] = {}   # {"used": bool, "mismatched_frames": int} of the last Flow call (tests, bench)
 _DEVICE_PLAN_MAX_FRAMES = 4096          # plan_kernel keeps the path [frames, 4] fp64 in LDS
+_DEVICE_PLAN_MAX_SEGMENTS = 64          # plan_kernel's segment table (PLAN_MAX_SEG in csrc/vstab_traj.hip): ranks of a sharded run
 
 
-def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, total_frames: int) -> bool:
-    LAST_DEVICE_PLAN.clear()
-    LAST_DEVICE_PLAN.update({"used": False, "mismatched_frames": 0})
+def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, total_frames: int, segments: int = 1) -> bool:
+    """Whether the speculative device plan covers this call.  `segments`: the ranks whose record blocks plan_kernel would
+    read from an all-gather's receive buffer (a world beyond its segment table takes the host-plan form, which has no limit).
+    What a call did is reported in its result (`StabilizationResult.device_plan`, `stats["device_plan"]` of a sharded call):
+    {"used": bool, "mismatched_frames": int} -- there is no module-level record."""
     return (os.environ.get("VSTAB_DEVICE_PLAN", "1") not in ("0", "false", "False") and estimator == "flow"
             and framing_mode == "crop_and_pad" and transform_mode in ("translation", "similarity")
-            and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES)
+            and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES and 1 <= segments <= _DEVICE_PLAN_MAX_SEGMENTS)
 
 
 def _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb) -> int:
@@ -503,14 +505,13 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
                               keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
     meta = prepare_meta(plan)                               # host JSON work overlaps the warp kernel
     final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
-    LAST_DEVICE_PLAN.update({"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask,
-                                                                                   counts, padding_rgb)})
+    verdict = {"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb)}
     meta = complete_meta(meta, plan, counts.cpu().numpy())
     _replay_progress(pbar, progress_done, total_frames, progress_total)
     check_interrupt()
     if keep_on_device:
-        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
-    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)
+        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta, verdict)
+    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta, verdict)
 
 
 def _stabilize_frames(
@@ -628,6 +629,7 @@ def _stabilize_frames(
     meta = complete_meta(meta, plan, counts.cpu().numpy())
     progress_done = _replay_progress(pbar, progress_done, total_frames, progress_total)
     check_interrupt()
+    verdict = {"used": False, "mismatched_frames": 0}
     if keep_on_device:
-        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta)
-    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta)
+        return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta, verdict)
+    return hm.StabilizationResult(dst.cpu().numpy(), mask.cpu().numpy()[..., np.newaxis], meta, verdict)

@@ -71,6 +71,9 @@ class StabilizationResult:
     frames: Any
     masks: Any
     meta: Dict[str, Any]
+    # what the speculative device plan did in this call ({"used": bool, "mismatched_frames": int}; None where no warp ran:
+    # empty / single-frame / bypassed clips) -- flow_pipeline: "the plan formed on the device, speculatively"
+    device_plan: Optional[Dict[str, Any]] = None
 
 
 # --------------------------------------------------------------------------- input adaptation (F0)

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Optional
+from typing import Any, Dict, Optional
 
 import numpy as np
 
@@ -94,6 +94,7 @@ def fit_table_to_dicts(table: np.ndarray):
 
 _SIGNATURES = {
     "vstab_abi_version": (C.c_int, []),
+    "vstab_test_hooks": (C.c_int, []),
     "vstab_last_error": (C.c_char_p, []),
     "vstab_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "vstab_destroy": (C.c_int, [C.c_void_p]),
@@ -320,8 +321,29 @@ class Context:
     def synchronize(self) -> None:
         _check(self.lib.vstab_synchronize(self.handle), "vstab_synchronize")
 
-    def set_timing(self, enabled: bool) -> None:
-        _check(self.lib.vstab_set_timing(self.handle, 1 if enabled else 0), "vstab_set_timing")
+    def set_timing(self, enabled: bool, detail: bool = False) -> None:
+        """detail: also bracket the stages inside a DIS call (a measurement pass of its own: see vstab.h)."""
+        _check(self.lib.vstab_set_timing(self.handle, (2 if detail else 1) if enabled else 0), "vstab_set_timing")
+
+    def dis_stage_ms(self) -> Dict[str, Any]:
+        """Milliseconds of the stages of the last DIS call under set_timing(True, detail=True):
+        {"prep": pyramid + coarsest level's preparation, "pis4": {"L5": .., ..}, "level": {..}, "final": ..} -- levels by
+        pyramid index (2 = the finest of the default configuration)."""
+        def ms(kind):
+            out = C.c_float()
+            return float(out.value) if self.lib.vstab_last_kernel_ms(self.handle, kind.encode(), C.byref(out)) == 0 else None
+
+        res: Dict[str, Any] = {"prep": ms("dis_prep"), "pis4": {}, "level": {}, "final": ms("dis_final")}
+        for lvl in range(16):
+            for stage in ("pis4", "level"):
+                v = ms(f"dis_{stage}_L{lvl}")
+                if v is not None:
+                    res[stage][f"L{lvl}"] = round(v, 4)
+        for k in ("prep", "final"):
+            res[k] = round(res[k], 4) if res[k] is not None else None
+        res["pis4_total"] = round(sum(res["pis4"].values()), 4)
+        res["level_total"] = round(sum(res["level"].values()), 4)
+        return res
 
     def last_kernel_ms(self, kind: str) -> float:
         out = C.c_float()

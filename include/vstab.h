@@ -51,13 +51,19 @@ enum vstab_mode { VSTAB_MODE_TRANSLATION = 0, VSTAB_MODE_SIMILARITY = 1, VSTAB_M
 int vstab_abi_version(void);
 const char* vstab_last_error(void);
 /* device < 0: use the current HIP device */
+/* 1 in the test build (-DVSTAB_TEST_HOOKS -> lib/libvstab_hooks.so: the fault injectors VSTAB_DEBUG_PLAN_PERTURB,
+ * VSTAB_DEBUG_PIS_SPIN_LIMIT, VSTAB_DEBUG_XFER_SPAWN_FAIL are read from the environment), 0 in the shipped library,
+ * which reads none of them. */
+int vstab_test_hooks(void);
 int vstab_create(vstab_ctx** out, int device);
 int vstab_destroy(vstab_ctx* ctx);
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
 int vstab_set_stream(vstab_ctx* ctx, void* hip_stream);
 int vstab_synchronize(vstab_ctx* ctx);
 /* Kernel timing with HIP events recorded on the call's own stream, per kind of call ("warp", "warp_blur",
- * "gray", "dis", "fit", "gftt", "lk", "phase").  vstab_set_timing(ctx, 1) enables it and clears the totals.
+ * "gray", "dis", "fit", "gftt", "lk", "phase").  vstab_set_timing(ctx, 1) enables it and clears the totals;
+ * vstab_set_timing(ctx, 2) also brackets the stages INSIDE a DIS call ("dis_prep", "dis_pis4_L<level>",
+ * "dis_level_L<level>", "dis_final": for a measurement pass of its own, the events lengthen the chain).
  * vstab_last_kernel_ms: milliseconds of the most recent call of that kind (waits for it to finish).
  * vstab_kernel_ms_stats: sum and number of all calls of that kind since timing was enabled -- no
  * synchronisation is needed inside a timed loop, bench.py reads the totals after its closing fence

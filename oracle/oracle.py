@@ -82,7 +82,13 @@ def _ptr(a, ty):
 
 
 def set_threads(n: int) -> None:
+    """OpenMP threads of the oracle's parallel loops: through the environment before the runtime starts, and through
+    omp_set_num_threads once it has (the environment variable is read only once per process)."""
     os.environ["OMP_NUM_THREADS"] = str(int(n))
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
 
 
 # ---------------------------------------------------------------- warp

@@ -511,3 +511,27 @@ def test_roofline_traffic_is_tied_to_the_warp_sources(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "warp_source_sha256", lambda: "0" * 64)
     traffic, why = bench.warp_traffic_record(256, 1920, 1080)
     assert traffic is None and "other warp kernel sources" in why
+
+
+def test_shipped_library_has_no_fault_injectors(pkg):
+    """the VSTAB_DEBUG_* fault injectors are compiled out of the shipped library; only the test build
+    (lib/libvstab_hooks.so, -DVSTAB_TEST_HOOKS, loaded by the tests that need them in a child process) reads them."""
+    import ctypes
+
+    from vstab_amd import native
+
+    lib_dir = native.LIB_PATH.parent
+    shipped, hooks = lib_dir / "libvstab.so", lib_dir / "libvstab_hooks.so"
+    assert shipped.exists() and hooks.exists(), "run __graft_entry__.build()"
+    assert b"VSTAB_DEBUG_" not in shipped.read_bytes()
+    blob = hooks.read_bytes()
+    for knob in (b"VSTAB_DEBUG_PLAN_PERTURB", b"VSTAB_DEBUG_PIS_SPIN_LIMIT", b"VSTAB_DEBUG_XFER_SPAWN_FAIL"):
+        assert knob in blob
+    assert ctypes.CDLL(str(shipped)).vstab_test_hooks() == 0
+    # (the hooks build is a second copy of the same exported symbols: query it in a child so that this process keeps one library)
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", f"import ctypes; print(ctypes.CDLL({str(hooks)!r}).vstab_test_hooks())"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "1", out.stderr[-2000:]

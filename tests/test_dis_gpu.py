@@ -114,31 +114,51 @@ def test_dis_recovers_known_translation(ctx):
 def test_expired_dependency_wait_is_reported(pkg):
     """Fail loudly: when a bounded LDS progress wait of the patch search expires, the kernel records it
     in the context's host-visible status word and the next synchronising call (the fit) returns non-zero with
-    vstab_last_error() set -- instead of handing back a wrong flow with rc 0.  VSTAB_DEBUG_PIS_SPIN_LIMIT=0 makes every
-    not-yet-satisfied wait expire at once (a debug knob read per call; a 540x960 portrait clip, whose stripes have eight
-    patch rows at the finest level: two wavefronts share a stripe and wait on each other's rows).  The status word is
-    cleared by the report, and the same context computes the same flow as before afterwards."""
+    vstab_last_error() set -- instead of handing back a wrong flow with rc 0.  The TEST build's VSTAB_DEBUG_PIS_SPIN_LIMIT=0
+    makes every not-yet-satisfied wait expire at once (a 540x960 portrait clip, whose stripes have eight patch rows at the
+    finest level: two wavefronts share a stripe and wait on each other's rows).  The status word is cleared by the report,
+    and the same context computes the same flow as before afterwards.  The shipped library has no such knob: the same
+    variable leaves its results unchanged."""
     import os
 
     import torch
+    from tests.util import run_with_hooks
     from vstab_amd import native
 
+    run_with_hooks("""
+        from tests.test_dis_gpu import moving_clip
+        ctx = native.Context()
+        gray, _ = moving_clip(3, 960, 540, seed=7)
+        dev = torch.from_numpy(gray).cuda()
+        _, clean = ctx.dis_flow_batch(dev, sample_step=8)
+        ctx.sample_fit_batch(clean, 8, "similarity")
+        clean = clean.clone()
+        os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"] = "0"
+        _, grid = ctx.dis_flow_batch(dev, sample_step=8)
+        try:
+            ctx.sample_fit_batch(grid, 8, "similarity")
+            raise SystemExit("the expired wait was not reported")
+        except native.VstabError as exc:
+            assert "expired dependency wait" in str(exc), exc
+        del os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"]
+        _, grid = ctx.dis_flow_batch(dev, sample_step=8)
+        ctx.sample_fit_batch(grid, 8, "similarity")          # no stale report
+        ctx.synchronize()
+        assert torch.equal(grid, clean)
+        ctx.close()
+    """)
+    assert native.load_library().vstab_test_hooks() == 0
     ctx = native.Context()
     gray, _ = moving_clip(3, 960, 540, seed=7)
     dev = torch.from_numpy(gray).cuda()
     _, clean = ctx.dis_flow_batch(dev, sample_step=8)
-    ctx.sample_fit_batch(clean, 8, "similarity")
     clean = clean.clone()
     os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"] = "0"
     try:
         _, grid = ctx.dis_flow_batch(dev, sample_step=8)
-        with pytest.raises(native.VstabError, match="expired dependency wait"):
-            ctx.sample_fit_batch(grid, 8, "similarity")
+        ctx.sample_fit_batch(grid, 8, "similarity")          # nothing injected, nothing reported
     finally:
         del os.environ["VSTAB_DEBUG_PIS_SPIN_LIMIT"]
-    _, grid = ctx.dis_flow_batch(dev, sample_step=8)
-    ctx.sample_fit_batch(grid, 8, "similarity")          # no stale report
-    ctx.synchronize()
     assert torch.equal(grid, clean)
     ctx.close()
 

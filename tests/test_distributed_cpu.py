@@ -79,7 +79,8 @@ def _worker(rank, world, port, total_frames, result_dir):
 
         local_counts = torch.from_numpy((np.arange(start, end, dtype=np.int64) % 5).astype(np.int32))
         fetch = vd._start_gather_counts(local_counts, vd.frame_counts(total_frames, world))   # host rows with gloo
-        all_counts = fetch()
+        all_counts, failed_ranks = fetch()
+        assert failed_ranks == []
         meta = fp.finish_meta(plan, all_counts)
         np.save(Path(result_dir) / f"final_{rank}.npy", np.stack(plan.final_matrices))
         import json
@@ -141,3 +142,82 @@ def test_shard_geometry(pkg):
         for k in a:
             assert np.array_equal(a[k]["matrix"], b[k]["matrix"]) and a[k]["confidence"] == b[k]["confidence"]
             assert a[k]["accepted"] == b[k]["accepted"]
+
+
+def _failure_worker(rank, world, port, total_frames, result_dir):
+    """Rank 1 fails (a) before the first collective, (b) between the two; both ranks must leave each exchange with the same
+    ShardError naming rank 1 -- nobody waits for a peer that has already raised."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import json
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    from vstab_amd import distributed as vd
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    out = {}
+    try:
+        full = fake_records(total_frames)
+        counts = vd.transition_counts(total_frames, world)
+        first = sum(counts[:rank])
+        local = full[first:first + counts[rank]]
+        # (a) the estimation of rank 1 raised: it still joins the exchange, with its status row
+        t0 = time.perf_counter()
+        try:
+            vd.gather_fit_records(None if rank == 1 else local, total_frames, failure=RuntimeError("DIS went wrong on purpose") if rank == 1 else None)
+            out["a"] = "no error"
+        except vd.ShardError as exc:
+            out["a"] = {"failed": exc.failed, "text": str(exc), "s": time.perf_counter() - t0}
+        # (a') a rank that hands in the wrong number of transitions is a failure of that rank, reported the same way
+        try:
+            vd.gather_fit_records(local[:-1] if rank == 1 else local, total_frames)
+            out["a2"] = "no error"
+        except vd.ShardError as exc:
+            out["a2"] = {"failed": exc.failed}
+        # the exchange works again afterwards (no half-consumed state)
+        assert len(vd.gather_fit_records(local, total_frames)) == total_frames - 1
+        # (b) rank 1 failed between the collectives: its status word travels with its (zero) counts
+        start, end = vd.shard_range(total_frames, world, rank)
+        local_counts = torch.zeros((end - start,), dtype=torch.int32) if rank == 1 else torch.arange(end - start, dtype=torch.int32)
+        fetch = vd._start_gather_counts(local_counts, vd.frame_counts(total_frames, world), failed=(rank == 1))
+        all_counts, bad = fetch()
+        out["b"] = {"bad": bad, "n": int(len(all_counts))}
+        fetch = vd._start_gather_counts(local_counts, vd.frame_counts(total_frames, world))
+        out["c"] = {"bad": fetch()[1]}
+        (Path(result_dir) / f"failure_{rank}.json").write_text(json.dumps(out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_is_reported_to_every_rank_through_the_collectives(pkg, tmp_path):
+    import json
+
+    import torch.multiprocessing as mp
+
+    world, total = 2, 23
+    mp.spawn(_failure_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        out = json.loads((tmp_path / f"failure_{rank}.json").read_text())
+        assert out["a"]["failed"] == [[1, "RuntimeError: DIS went wrong on purpose"]], out
+        assert "rank 1" in out["a"]["text"] and out["a"]["s"] < 5.0
+        assert [r for r, _ in out["a2"]["failed"]] == [1] and "expected" in out["a2"]["failed"][0][1]
+        assert out["b"] == {"bad": [1], "n": total} and out["c"] == {"bad": []}
+
+
+def test_status_rows_round_trip(pkg):
+    from vstab_amd import distributed as vd
+
+    ok = vd._status_row(216, None)
+    assert not ok.any() and vd._failed_ranks(np.stack([ok, ok])) == []
+    long = ValueError("x" * 1000)
+    rows = np.stack([ok, vd._status_row(216, long), vd._status_row(216, KeyError("k"))])
+    failed = vd._failed_ranks(rows)
+    assert [r for r, _ in failed] == [1, 2] and failed[0][1].startswith("ValueError: xxx") and len(failed[0][1]) == 216 - 4
+    assert failed[1][1] == "KeyError: 'k'"

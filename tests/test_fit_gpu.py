@@ -84,9 +84,10 @@ def test_fit_too_few_valid_points(ctx):
 @pytest.mark.parametrize("smooth,fps", [(0.0, 16.0), (0.5, 16.0), (1.0, 24.0), (0.5, 60.0), (0.3, 30.0)])
 @pytest.mark.parametrize("p,n", [(2, 97), (4, 97), (8, 97), (4, 2048), (8, 2048), (8, 5000)])
 def test_trajectory_matches_numpy(ctx, smooth, fps, p, n):
-    """fp64 restatement of flow.py:356-371 + utils.py:361-383 written with NumPy in the test.  The sizes cover the
-    kernel with the path in LDS (below and above the 64 KB default limit) and the global-memory kernel for paths that
-    do not fit (8 x 5000 doubles)."""
+    """fp64 restatement of flow.py:356-371 + utils.py:361-383 written with NumPy in the test, against `vstab_trajectory`
+    -- HOST arithmetic since round 4 (csrc/vstab_traj.hip: the same operation order as plan_kernel, no launch; the device
+    form is tied to it by tests/test_device_plan_gpu.py).  The sizes once selected between an LDS and a global-memory
+    kernel; they stay as short / long / wide paths (up to 8 x 5000 doubles)."""
     rng = np.random.default_rng(int(fps) + p)
     deltas = rng.normal(0, 1.5, (n - 1, p))
     path, target = ctx.trajectory(deltas, smooth, fps, 0.7, False)
@@ -109,12 +110,15 @@ def test_trajectory_matches_numpy(ctx, smooth, fps, p, n):
 
 
 def test_trajectory_matches_reference_smooth_golden(ctx):
-    """F8 pinned: the shipped trajectory kernel against the 60 outputs of the REFERENCE's own `_smooth_path`
-    (nodes/stabilizer_utils.py:361-383; tests/golden/reference_helpers.json["smooth"], generated by make_golden.py:95-99
-    from the imported reference).  vstab_trajectory takes per-frame deltas and starts its path at 0, so each golden
-    path is fed as np.diff and its first row is added back; with strength 1 the target IS the smoothed path
-    (flow.py:368: path + 1*(smooth - path)).  Tolerance 1e-12 absolute on values of magnitude <= 30: the golden is
-    np.convolve's summation order, the kernel's is a sequential window sum (observed difference <= 1e-14)."""
+    """F8 pinned: the shipped `vstab_trajectory` (the host form every plan the node returns is made with) against the 60
+    outputs of the REFERENCE's own `_smooth_path` (nodes/stabilizer_utils.py:361-383;
+    tests/golden/reference_helpers.json["smooth"], generated by make_golden.py:95-99 from the imported reference).
+    vstab_trajectory takes per-frame deltas and starts its path at 0, so each golden path is fed as np.diff and its first
+    row is added back; with strength 1 the target IS the smoothed path (flow.py:368: path + 1*(smooth - path)).
+    Tolerance 1e-12 absolute on values of magnitude <= 30: the golden is np.convolve's summation order, the library's a
+    sequential window sum (observed difference <= 1e-14).  The speculative device form (plan_kernel) holds this pin only
+    through its tie to the host form: bit-equal on translation deltas, within 16 ulp on similarity deltas
+    (tests/test_device_plan_gpu.py::test_host_trajectory_*)."""
     import json
     from pathlib import Path
 

@@ -49,14 +49,13 @@ def _worker(rank, world, port, out_dir, estimator, framing="expand", keep_fov=0.
         start, end = vd.shard_range(n, world, rank)
         halo = 1 if (rank > 0 and end > start) else 0
         local = torch.from_numpy(frames[start - halo:end]).cuda()
+        stats = {}
         dst, mask, meta = vd.stabilize_sharded(ctx, local, n, framing, "similarity", False, 0.7, 0.5, keep_fov, (127, 127, 127), 16.0,
-                                               estimator=estimator)
+                                               estimator=estimator, stats=stats)
         np.save(Path(out_dir) / f"dst_{rank}.npy", dst.cpu().numpy())
         np.save(Path(out_dir) / f"mask_{rank}.npy", mask.cpu().numpy())
         (Path(out_dir) / f"meta_{rank}.json").write_text(json.dumps(meta))
-        from vstab_amd import flow_pipeline as fp_
-
-        (Path(out_dir) / f"device_plan_{rank}.json").write_text(json.dumps(fp_.LAST_DEVICE_PLAN))
+        (Path(out_dir) / f"device_plan_{rank}.json").write_text(json.dumps(stats.get("device_plan")))
         if backend == "nccl":   # the replay half of BASELINE C5 under the same process group (it issues no collective)
             from vstab_amd import apply_pipeline as ap
 
@@ -304,7 +303,7 @@ def test_c4_sized_clip_two_ranks_equal_single_process(pkg, ctx, tmp_path):
     del frames
     # the single-process side ran on the device-formed plan (the two ranks above form theirs on the host) and none of the
     # 1024 device matrices differed from the host's: the equality below is the speculation holding, not its fallback
-    assert fp.LAST_DEVICE_PLAN == {"used": True, "mismatched_frames": 0}
+    assert res.device_plan == {"used": True, "mismatched_frames": 0}
     want_dst, want_mask = _frame_checksums(res.frames), _frame_checksums(res.masks)
     parts = [torch.load(tmp_path / f"c4_{r}.pt") for r in range(2)]
     assert [p["start"] for p in parts] == [0, 512]
@@ -338,3 +337,91 @@ def test_bench_default_multi_rank_line_rehearsed_on_one_gpu():
     assert c4["same_clip_on_one_gpu"]["ms_per_step"] > 0 and "rank0_host_ms" in c4
     c5 = line["c5"]
     assert "error" not in c5 and c5["total_frames"] == 4 and c5["n_gpus"] == 2 and c5["value"] > 0
+
+
+def _failing_worker(rank, world, port, out_dir, where, form):
+    """Both ranks on cuda:0 (gloo control plane).  After one clean call, rank 1 alone fails at `where`; every rank must come
+    out of stabilize_sharded with a ShardError naming rank 1, quickly, and the next clean call must work again."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if form == "device_plan":
+        os.environ["VSTAB_SHARDED_DEVICE_PLAN"] = "force"
+    import datetime
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    from vstab_amd import distributed as vd
+    from vstab_amd import native
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        ctx = native.Context(0)
+        frames = _clip()
+        n = frames.shape[0]
+        start, end = vd.shard_range(n, world, rank)
+        halo = 1 if (rank > 0 and end > start) else 0
+        local = torch.from_numpy(frames[start - halo:end]).cuda()
+        args = (ctx, local, n, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+        clean = vd.stabilize_sharded(*args)
+        out = {"form_taken": None}
+        if rank == 1:   # the injected failure: an exception out of one library call of this rank only
+            target = {"estimate": "dis_flow_batch", "fit_end": "sample_fit_batch_end" if form == "device_plan" else "sample_fit_batch",
+                      "warp": "warp_batch_planned" if form == "device_plan" else "warp_batch"}[where]
+            real = getattr(ctx, target)
+
+            def boom(*a, **k):
+                raise native.VstabError(f"injected failure in {target}")
+
+            setattr(ctx, target, boom)
+        t0 = time.perf_counter()
+        try:
+            vd.stabilize_sharded(*args)
+            out["error"] = None
+        except vd.ShardError as exc:
+            out["error"] = {"failed": exc.failed, "text": str(exc)}
+        out["seconds"] = time.perf_counter() - t0
+        if rank == 1:
+            setattr(ctx, target, real)
+        stats = {}
+        again = vd.stabilize_sharded(*args, stats=stats)
+        out["form_taken"] = stats["device_plan"]["used"]
+        out["again_equal"] = bool(torch.equal(again[0], clean[0]) and torch.equal(again[1], clean[1]) and again[2] == clean[2])
+        (Path(out_dir) / f"failing_{rank}.json").write_text(json.dumps(out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form,where", [("host_plan", "estimate"), ("host_plan", "warp"), ("device_plan", "estimate"),
+                                        ("device_plan", "fit_end"), ("device_plan", "warp")])
+def test_a_rank_that_fails_alone_fails_every_rank_and_nobody_hangs(pkg, ctx, tmp_path, monkeypatch, form, where):
+    """`sample_fit_batch_end` (DIS status), the estimation or the warp raising on ONE rank used to leave
+    the peers in a collective until the process group's timeout.  The status row / status word that now travels with the two
+    all-gathers makes every rank raise the same ShardError -- in both forms of the sharded path, before the first collective
+    (reported through it) and between the two (reported through the second) -- within seconds, and the group stays usable."""
+    import torch.multiprocessing as mp
+
+    if form == "host_plan":
+        monkeypatch.setenv("VSTAB_DEVICE_PLAN", "0")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_failing_worker, args=(2, port, str(tmp_path), where, form), nprocs=2, join=True)
+    for rank in range(2):
+        out = json.loads((tmp_path / f"failing_{rank}.json").read_text())
+        assert out["error"] is not None, out
+        assert [r for r, _ in out["error"]["failed"]] == [1], out
+        assert out["seconds"] < 5.0, out
+        assert out["again_equal"] and out["form_taken"] == (form == "device_plan")
+        if where == "estimate":   # reported through the fit-record exchange, with the text
+            assert "injected failure in dis_flow_batch" in out["error"]["failed"][0][1]
+            assert "before the exchange" in out["error"]["text"]
+        else:
+            assert "between its two collectives" in out["error"]["text"]
+    own = json.loads((tmp_path / "failing_1.json").read_text())["error"]["failed"][0][1]
+    assert "injected failure" in own

@@ -88,3 +88,38 @@ def shake_path(n, w, h, kind, seed=3, amp=1.0):
         post = np.array([[1, 0, w / 2 + tx], [0, 1, h / 2 + ty], [0, 0, 1.0]])
         out[i] = post @ np.array([[c, -s, 0], [s, c, 0], [px, py, 1.0]]) @ pre
     return out
+
+
+HOOKS_PRELUDE = """
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+import __graft_entry__ as graft
+graft.load_package()
+from vstab_amd import native
+assert native.load_library().vstab_test_hooks() == 1, "this child needs the test build (lib/libvstab_hooks.so)"
+"""
+
+
+def run_with_hooks(body: str, env=None, timeout=600):
+    """Run `body` (Python source) in a child process that loads the TEST build of the library (lib/libvstab_hooks.so, the
+    same sources with -DVSTAB_TEST_HOOKS: the fault injectors VSTAB_DEBUG_* exist only there; the shipped libvstab.so reads
+    none of them).  `env`: extra environment of the child.  Returns its stdout; a failing child fails the test with its output."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    lib = root / "comfyui-video-stabilizer_amd" / "lib" / "libvstab_hooks.so"
+    if not lib.exists():
+        import __graft_entry__ as graft
+
+        graft.build()
+    child_env = dict(os.environ)
+    child_env.update({"VSTAB_LIB": str(lib)}, **(env or {}))
+    proc = subprocess.run([sys.executable, "-c", HOOKS_PRELUDE.format(root=str(root)) + textwrap.dedent(body)], env=child_env,
+                          capture_output=True, text=True, timeout=timeout, cwd=str(root))
+    assert proc.returncode == 0, proc.stdout[-3000:] + "\n" + proc.stderr[-6000:]
+    return proc.stdout

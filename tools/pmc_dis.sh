@@ -10,6 +10,7 @@
 # -- NOT "SQ_ACTIVE_INST_VALU x 4 / (1024 x cycles)", the formula of rounds 2-3, which exceeds 1 on the blur kernel.
 R=$GRAFT_REPO_ROOT
 source $R/tools/pmc_lib.sh
+pmc_prepare
 TAG=${1:-r04}
 OUT=$R/gpurun_out/pmc_$TAG
 DIRS=""

@@ -16,6 +16,11 @@
 #     queued behind an event of another queue can wait for a kernel the serialiser holds back.  That cause is a reading of
 #     two incidents, not a demonstrated one; nothing here tries to make it happen again.
 export VSTAB_DIS_PREP_STREAM=0
+# the clip of tools/pmc_target.py is synthesised ONCE, unprofiled, and parked under /tmp: the profiled process then loads it
+# with a few copies instead of ~10^4 torch dispatches under counter collection (tools/pmc_make_clip.py)
+pmc_prepare() {
+  ( cd "$GRAFT_REPO_ROOT" && timeout -k 10 300 python3 tools/pmc_make_clip.py 256 ) || { echo "pmc_prepare: could not park the clip (the target will synthesise it itself)"; return 0; }
+}
 pmc_pass() {
   local out=$1 label=$2 limit=$3 counters=$4; shift 4
   local stamp; stamp=$(date +%Y%m%d-%H%M%S)_$$

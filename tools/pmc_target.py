@@ -1,10 +1,22 @@
-"""Workload for the PMC passes of tools/pmc_dis.sh: two Flow passes (C2, 256 x 1080p) and one Motion Apply pass
-(C3 kind: bicubic, blur 0.5, 17 samples, 64 x 1080p) so that level_kernel, pis4_kernel and the blur warp kernel
-each appear a few times.  Run directly under rocprofv3 (`-- python3 tools/pmc_target.py`)."""
-import json, sys
+"""Workload for the PMC passes of tools/pmc_dis.sh / pmc_traffic.sh: two Flow passes (C2, 256 x 1080p) and one Motion Apply
+pass (C3 kind: bicubic, blur 0.5, 17 samples, 64 x 1080p) so that level_kernel, pis4_kernel and the blur warp kernel each
+appear a few times.  Run directly under rocprofv3 (`-- python3 tools/pmc_target.py`).
+
+Built so that a pass that stalls says WHERE (three passes were killed at their limit in rounds 2-4; their logs ended at "clip
+ready", printed after the clip's kernels were QUEUED, not finished -- so the stall was somewhere between the first synthesis
+kernel and the first library kernel, location unknown; profiles/r04_pmc_failed_pass/README.md):
+  * the context is created and ONE trivial library kernel is launched and waited for before anything else runs: the
+    library's code object is loaded, and its first dispatch is profiled, while nothing else is in flight;
+  * the clip comes from /tmp (tools/pmc_make_clip.py, run unprofiled by tools/pmc_lib.sh) through a few large copies; only if
+    that file is missing is it synthesised here, with a synchronisation and a line every 32 frames;
+  * every stage ends in a host synchronisation and a line;
+  * faulthandler dumps every thread's Python stack after 150 s without finishing, i.e. before the pass's 200 s limit."""
+import faulthandler, json, sys
 from pathlib import Path
+faulthandler.dump_traceback_later(150, exit=False)
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+import numpy as np
 import torch
 import __graft_entry__ as graft
 graft.load_package()
@@ -16,6 +28,9 @@ def say(msg):
 
 
 ctx = native.Context(0)
+tiny = torch.zeros((2, 8, 16, 3), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize(); say("device up, torch's first kernels done")
+ctx.frame_range(tiny); ctx.synchronize(); say("first library kernel done (code object loaded)")
 
 
 def _settled(t):
@@ -25,10 +40,21 @@ def _settled(t):
     hm.resolve_value_range(c)
     return c
 
-frames = bench.synth_clip(256, 0, 1080, 1920, torch.device("cuda", 0))
-say("clip ready")
-# the library's stages once, one at a time with a host synchronisation and a line after each: a pass that is killed at its
-# time limit shows which stage it was in (the two earlier incidents left only "clip ready")
+N = 256
+parked = Path(f"/tmp/vstab_pmc_clip_{N}.npy")
+if parked.exists():
+    host = np.load(parked, mmap_mode="r")
+    frames = torch.empty((N, 1080, 1920, 3), dtype=torch.float32, device="cuda")
+    for a in range(0, N, 32):
+        frames[a:a + 32].copy_(torch.from_numpy(np.ascontiguousarray(host[a:a + 32])))
+    torch.cuda.synchronize(); say("clip loaded from /tmp (8 copies, no synthesis kernels under the profiler)")
+else:
+    parts = []
+    for a in range(0, N, 32):
+        parts.append(bench.synth_clip(32, a, 1080, 1920, torch.device("cuda", 0)))
+        torch.cuda.synchronize(); say(f"clip synthesised up to frame {a + 32}")
+    frames = torch.cat(parts); del parts
+    torch.cuda.synchronize(); say("clip synthesised")
 work = hm._working_estimation_size(1920, 1080)
 gray = ctx.gray_downscale(frames, work); ctx.synchronize(); say("stage gray done")
 _, grid = ctx.dis_flow_batch(gray, sample_step=fp.SAMPLE_STEP, want_full=False, want_grid=True); ctx.synchronize(); say("stage dis done")
@@ -50,4 +76,5 @@ r = ap.apply_motion(_settled(frames[:64]), meta, (127, 127, 127), framing_mode="
                     motion_blur=0.5, motion_blur_samples=17, ctx=ctx, keep_on_device=True)
 ctx.synchronize()
 say("motion apply pass done, device status clean")
+faulthandler.cancel_dump_traceback_later()
 print("done")

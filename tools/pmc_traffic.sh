@@ -4,6 +4,7 @@
 #   usage: tools/pmc_traffic.sh <tag>   -> gpurun_out/<tag>_hbm_traffic.csv (per-dispatch means, KB as the counters report)
 R=$GRAFT_REPO_ROOT
 source $R/tools/pmc_lib.sh
+pmc_prepare
 TAG=${1:-r04}
 OUT=$R/gpurun_out/pmc_traffic_$TAG
 declare -A DIRS
