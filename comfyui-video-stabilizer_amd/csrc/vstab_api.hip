@@ -154,8 +154,11 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->d_range.release();
     ctx->d_plan.release();
     ctx->h_plan.release();
+    if (ctx->h_peaks) (void)hipHostFree(ctx->h_peaks);
     if (ctx->ev_fit_done) (void)hipEventDestroy(ctx->ev_fit_done);
     if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
     for (auto& kv : ctx->timers) { (void)hipEventDestroy(kv.second.start); (void)hipEventDestroy(kv.second.stop); }
     (void)hipEventDestroy(ctx->ev_params_free);
     if (ctx->h_status) (void)hipHostFree(const_cast<int*>(ctx->h_status));
@@ -189,7 +192,8 @@ int vstab_set_timing(vstab_ctx* ctx, int enabled)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_set_timing: ctx is NULL");
     ctx->timing = enabled != 0;
-    ctx->timing_detail = enabled >= 2;
+    ctx->timing_detail = enabled == 2;
+    ctx->timing_warp_only = enabled == 3;
     for (auto& kv : ctx->timers) { kv.second.pending = false; kv.second.total_ms = 0.0; kv.second.launches = 0; }
     return 0;
 }

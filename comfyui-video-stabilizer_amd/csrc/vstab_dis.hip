@@ -213,6 +213,88 @@ __global__ __launch_bounds__(256) void area_general_rows_kernel(const uint8_t* _
     }
 }
 
+// ---- the pyramid's tail in ONE launch ------------------------------------------------------------------------------------
+// The levels above the finest one are tiny (120 x 67, 60 x 33, 30 x 16 for a 1080p clip) and each is the INTER_AREA of the
+// previous: as separate launches they are three latency-bound kernels in a row on the call's stream (28 + 16 + 6 us per
+// 256-frame clip, profiles/r05_dis_small_steps.md).  One workgroup per frame keeps the chain on chip: the finest level is
+// read into LDS once, every further level is formed from the previous one's LDS copy (tap tables of a level computed once
+// per workgroup, as in area_general_rows_kernel) and written to both LDS and its plane.  Per output the same taps, the same
+// f32 sums in the same order as area_u8_kernel's modes 0 / 1 / 2 (whichever launch_area would pick for that level).
+constexpr int TAIL_MAX_LEVELS = 8;
+struct TailLevel { uint8_t* dst; int h, w, mode, kx, ky; double scale_x, scale_y; };
+struct TailArgs {
+    const uint8_t* src;   // [n][h0][w0]: the finest level
+    int n, h0, w0, levels;
+    TailLevel lv[TAIL_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+    const int f = blockIdx.x;
+    const int cap0 = (a.h0 * a.w0 + 15) & ~15;                // level images ping-pong between two buffers
+    const int cap1 = (a.lv[0].h * a.lv[0].w + 15) & ~15;
+    unsigned char* bufA = tail_lds;
+    unsigned char* bufB = tail_lds + cap0;
+    AreaTaps* s_x = reinterpret_cast<AreaTaps*>(tail_lds + cap0 + cap1);
+    AreaTaps* s_y = s_x + a.lv[0].w;
+    {
+        const uint8_t* S = a.src + (size_t)f * a.h0 * a.w0;
+        const int npx = a.h0 * a.w0;
+        if ((reinterpret_cast<uintptr_t>(S) & 3) == 0 && (npx & 3) == 0) {
+            const unsigned* s4 = reinterpret_cast<const unsigned*>(S);
+            unsigned* d4 = reinterpret_cast<unsigned*>(bufA);
+            for (int k = threadIdx.x; k < npx / 4; k += blockDim.x) d4[k] = s4[k];
+        } else {
+            for (int k = threadIdx.x; k < npx; k += blockDim.x) bufA[k] = S[k];
+        }
+    }
+    __syncthreads();
+    int sh = a.h0, sw = a.w0;
+    unsigned char* cur = bufA;
+    unsigned char* nxt = bufB;
+    for (int l = 0; l < a.levels; l++) {
+        const TailLevel& L = a.lv[l];
+        const int dh = L.h, dw = L.w;
+        if (L.mode == 2) {
+            for (int x = threadIdx.x; x < dw; x += blockDim.x) area_taps(x, sw, L.scale_x, s_x[x]);
+            for (int y = threadIdx.x; y < dh; y += blockDim.x) area_taps(y, sh, L.scale_y, s_y[y]);
+            __syncthreads();
+        }
+        uint8_t* D = L.dst + (size_t)f * dh * dw;
+        for (int t = threadIdx.x; t < dh * dw; t += blockDim.x) {
+            const int y = t / dw, x = t - y * dw;
+            int o;
+            if (L.mode == 0) {
+                const unsigned char* s0 = cur + (2 * y) * sw + 2 * x;
+                o = (s0[0] + s0[1] + s0[sw] + s0[sw + 1] + 2) >> 2;
+            } else if (L.mode == 1) {
+                int sum = 0;
+                for (int j = 0; j < L.ky; j++)
+                    for (int i = 0; i < L.kx; i++) sum += cur[(y * L.ky + j) * sw + x * L.kx + i];
+                o = sat_u8_round(sum * (1.f / (L.kx * L.ky)));
+            } else {
+                const AreaTaps& ax = s_x[x];
+                const AreaTaps& ay = s_y[y];
+                float sum = 0.f;
+                for (int j = 0; j < ay.n; j++) {
+                    const unsigned char* row = cur + (ay.first + j) * sw + ax.first;
+                    float buf = 0.f;
+                    for (int k = 0; k < ax.n; k++) buf += row[k] * ax.a[k];
+                    const float term = ay.a[j] * buf;
+                    sum = (j == 0) ? term : sum + term;
+                }
+                o = sat_u8_round(sum);
+            }
+            nxt[t] = (unsigned char)o;
+            D[t] = (uint8_t)o;
+        }
+        __syncthreads();
+        unsigned char* tmp = cur; cur = nxt; nxt = tmp;
+        sh = dh; sw = dw;
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_replicate_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n, int h, int w)
 {
     const int we = w + 2 * DIS_BORDER, he = h + 2 * DIS_BORDER;
@@ -834,7 +916,7 @@ struct LevelArgs {
     float* nextU;       // [P][nh][nw] (finer level) or nullptr
     float* nextV;
     VrBufs vb;
-    int P, h, w, ws, hs, nh, nw;
+    int P, h, w, ws, hs, nh, nw, nhs, nws;   // n*: the next finer level (image size, patch grid)
     int tiles_x, tiles_y;   // SOR tiling (LDS temporal blocking)
     int lds_plane;          // floats per LDS plane (max padded tile)
     int parts;              // split launches: workgroups per pair of this launch (pixel slices, or tiles)
@@ -1172,16 +1254,17 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
 #undef LDF
     FUSED_MARK(7);
     if ((FUSED || MODE == LEVEL_UPSAMPLE) && a.nextU != nullptr) {
+        // The x2 upsampled flow is read at the finer level's PATCH CENTRES only -- the initial flow of its patch search,
+        // pis4_kernel's `U[(i + PSZ / 2) * w + j + PSZ / 2]` -- before that level's densification overwrites the whole
+        // plane: only those nhs x nws samples are evaluated (1 pixel in 16), each exactly as the dense resize forms it.
         const int nn = a.nh * a.nw;
         float* __restrict__ nU = a.nextU + (long long)pair * nn;
         float* __restrict__ nV = a.nextV + (long long)pair * nn;
-        const int up_dy = px_stride_ / a.nw, up_dx = px_stride_ - up_dy * a.nw;
-        int q_ = part * (int)blockDim.x + (int)threadIdx.x;
-        int dy = q_ / a.nw, dx = q_ - dy * a.nw;
-        for (; q_ < nn; q_ += px_stride_) {
-            upsample_px(U, V, nU, nV, q_, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
-            dx += up_dx; dy += up_dy;
-            if (dx >= a.nw) { dx -= a.nw; dy++; }
+        const int npts = a.nhs * a.nws;
+        for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npts; q_ += px_stride_) {
+            const int is = q_ / a.nws, js = q_ - is * a.nws;
+            const int dy = is * PSTR + PSZ / 2, dx = js * PSTR + PSZ / 2;
+            upsample_px(U, V, nU, nV, dy * a.nw + dx, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
         }
     }
 #ifdef VSTAB_FUSED_TRACE
@@ -1242,13 +1325,25 @@ struct Carver {
     }
 };
 
+// cv::resize(INTER_AREA) picks its path from the ratios: exact 2 x 2, exact integer boxes, or the general tap tables
+struct AreaPlan { double scale_x, scale_y; int isx, isy, mode; };
+int plan_area(int sh, int sw, int dh, int dw, AreaPlan& pl)
+{
+    pl.scale_x = 1. / ((double)dw / sw); pl.scale_y = 1. / ((double)dh / sh);
+    pl.isx = (int)std::lrint(pl.scale_x); pl.isy = (int)std::lrint(pl.scale_y);
+    const bool fast = std::fabs(pl.scale_x - pl.isx) < DBL_EPSILON && std::fabs(pl.scale_y - pl.isy) < DBL_EPSILON;
+    VSTAB_REQUIRE(pl.scale_x >= 1.0 && pl.scale_y >= 1.0 && pl.scale_x < 6.0 && pl.scale_y < 6.0, "dis: area ratio %.3fx%.3f unsupported", pl.scale_x, pl.scale_y);
+    pl.mode = fast ? ((pl.isx == 2 && pl.isy == 2) ? 0 : 1) : 2;
+    return 0;
+}
+
 int launch_area(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int sh, int sw, int dh, int dw)
 {
-    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
-    const bool fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
-    VSTAB_REQUIRE(scale_x >= 1.0 && scale_y >= 1.0 && scale_x < 6.0 && scale_y < 6.0, "dis: area ratio %.3fx%.3f unsupported", scale_x, scale_y);
-    int mode = fast ? ((isx == 2 && isy == 2) ? 0 : 1) : 2;
+    AreaPlan pl;
+    if (int rc = plan_area(sh, sw, dh, dw, pl)) return rc;
+    const double scale_x = pl.scale_x, scale_y = pl.scale_y;
+    const int isx = pl.isx, isy = pl.isy;
+    int mode = pl.mode;
     if (mode == 1 && isx == 4 && isy == 4 && sw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) mode = 3;
     const long long row_groups = (long long)n * ((dh + AREA_ROWS - 1) / AREA_ROWS);
     if (mode == 2 && dw <= AREA_MAX_COLS && row_groups < 0x7fffffffLL)
@@ -1347,10 +1442,38 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     }
     // (set_timing level 2 only: events around the stages of this call, vstab_internal.h)
     auto prep_timer = std::make_unique<DetailTimer>(ctx, "dis_prep");
-    for (int i = FINEST; i <= coarsest; i++) {
-        const LevelGeom& g = G[i];
-        if (i == FINEST) { if (launch_area(st, gray, I[i], n, h, w, g.h, g.w)) return 1; }
-        else { if (launch_area(st, I[i - 1], I[i], n, G[i - 1].h, G[i - 1].w, g.h, g.w)) return 1; }
+    {
+        if (launch_area(st, gray, I[FINEST], n, h, w, G[FINEST].h, G[FINEST].w)) return 1;
+        // the levels above the finest: one launch (pyramid_tail_kernel) where the finest level and its successor fit one
+        // workgroup's LDS -- every clip whose working size is DIS's usual <= 960 px -- else one launch per level
+        // (VSTAB_DIS_PYRAMID_TAIL=0 forces the latter: A/B measurement, tests)
+        static const bool tail_on = [] { const char* e = getenv("VSTAB_DIS_PYRAMID_TAIL"); return !(e && atoi(e) == 0); }();
+        const int tail_levels = coarsest - FINEST;
+        size_t tail_lds = 0;
+        if (tail_levels >= 1) {
+            const LevelGeom& a0 = G[FINEST];
+            const LevelGeom& a1 = G[FINEST + 1];
+            tail_lds = (((size_t)a0.h * a0.w + 15) & ~size_t(15)) + (((size_t)a1.h * a1.w + 15) & ~size_t(15)) +
+                       sizeof(AreaTaps) * ((size_t)a1.w + a1.h);
+        }
+        if (tail_on && tail_levels >= 1 && tail_levels <= TAIL_MAX_LEVELS && tail_lds <= 150 * 1024) {
+            TailArgs ta{};
+            ta.src = I[FINEST]; ta.n = n; ta.h0 = G[FINEST].h; ta.w0 = G[FINEST].w; ta.levels = tail_levels;
+            for (int i = FINEST + 1; i <= coarsest; i++) {
+                AreaPlan pl;
+                if (int rc = plan_area(G[i - 1].h, G[i - 1].w, G[i].h, G[i].w, pl)) return rc;
+                TailLevel& tl = ta.lv[i - FINEST - 1];
+                tl.dst = I[i]; tl.h = G[i].h; tl.w = G[i].w; tl.mode = pl.mode; tl.kx = pl.isx; tl.ky = pl.isy;
+                tl.scale_x = pl.scale_x; tl.scale_y = pl.scale_y;
+            }
+            if (tail_lds > 64 * 1024)
+                VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3((unsigned)n), dim3(256), tail_lds, st, ta);
+            VSTAB_HIP(hipGetLastError());
+        } else {
+            for (int i = FINEST + 1; i <= coarsest; i++)
+                if (launch_area(st, I[i - 1], I[i], n, G[i - 1].h, G[i - 1].w, G[i].h, G[i].w)) return 1;
+        }
     }
     if (two_streams) {
         // (the event also orders the second stream behind every earlier kernel of this stream that still reads the workspace)
@@ -1420,7 +1543,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         la.alpha2 = alpha2; la.delta2 = delta2; la.gamma2 = gamma2; la.zeta2 = zeta2; la.eps2 = eps2; la.omega = omega;
         if (i > FINEST) {
             const LevelGeom& d = G[i - 1];
-            la.nextU = Ul[i - 1]; la.nextV = Vl[i - 1]; la.nh = d.h; la.nw = d.w;
+            la.nextU = Ul[i - 1]; la.nextV = Vl[i - 1]; la.nh = d.h; la.nw = d.w; la.nhs = d.hs; la.nws = d.ws;
             la.up_sx = 1. / ((double)d.w / g.w); la.up_sy = 1. / ((double)d.h / g.h);
         }
         {   // smallest tiling whose padded tile fits SOR_TILE_CAP pixels (registers hold SOR_NPT pixels per colour)
@@ -1469,7 +1592,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             la.parts = px_parts;
             hipLaunchKernelGGL(level_kernel<LEVEL_MERGE>, dim3((unsigned)(P * px_parts)), dim3(FUSED_T), 0, st, la);
             if (la.nextU != nullptr) {
-                la.parts = std::max(1, std::min(64, (la.nh * la.nw + FUSED_T - 1) / FUSED_T));
+                la.parts = std::max(1, std::min(64, (la.nhs * la.nws + FUSED_T - 1) / FUSED_T));
                 hipLaunchKernelGGL(level_kernel<LEVEL_UPSAMPLE>, dim3((unsigned)(P * la.parts)), dim3(FUSED_T), 0, st, la);
             }
         }

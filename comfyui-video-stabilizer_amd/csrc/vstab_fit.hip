@@ -425,6 +425,10 @@ static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pai
                    int requested_mode, vstab_fit_record* results)
 {
     VSTAB_HIP(hipSetDevice(ctx->device));
+    // a pending fit whose records were downloaded on the side stream but never collected (a call abandoned between _begin
+    // and _end): that copy reads d_fit and has to be over before this call's kernels write it again
+    if (ctx->fit_pairs_pending > 0 && ctx->fit_copy_bytes == 0 && ctx->ev_fit_done) VSTAB_HIP(hipEventSynchronize(ctx->ev_fit_done));
+    ctx->fit_pairs_pending = 0; ctx->fit_copy_bytes = 0;
     const size_t rec_bytes = sizeof(vstab_fit_record) * (size_t)pairs * 3;
     const size_t map_bytes = sizeof(int) * (size_t)pairs * cap;
     if (ctx->d_fit.reserve(rec_bytes + map_bytes + 512)) return 1;
@@ -441,13 +445,16 @@ static int run_fit(vstab_ctx* ctx, const float* data, const int* counts, int pai
             if (int rc = vstab_fit_homography(ctx, data, d_map, pairs, gh, gw, step, cap, d_out)) return rc;
         }
     }
-    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (results == nullptr) {
+        // the records' download is NOT queued here: a copy on this stream would sit between the fit kernel and whatever the
+        // caller queues next (the plan kernel, the warp).  vstab_flow_plan_device issues it on the side stream behind the plan
+        // kernel; vstab_sample_fit_batch_end issues it itself if nobody has by then.
         if (!ctx->ev_fit_done) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_fit_done, hipEventDisableTiming));
-        VSTAB_HIP(hipEventRecord(ctx->ev_fit_done, ctx->stream));
         ctx->fit_pairs_pending = pairs;
+        ctx->fit_copy_bytes = rec_bytes;
         return 0;
     }
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, d_out, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(results, ctx->h_fit.ptr, rec_bytes);
     // the flow these fits were computed from was produced asynchronously by vstab_dis_flow_batch on the same stream:
@@ -494,6 +501,11 @@ extern "C" int vstab_sample_fit_batch_end(vstab_ctx* ctx, int pairs, vstab_fit_r
 {
     VSTAB_REQUIRE(ctx != nullptr && results != nullptr, "vstab_sample_fit_batch_end: NULL argument");
     VSTAB_REQUIRE(ctx->fit_pairs_pending > 0 && pairs == ctx->fit_pairs_pending, "vstab_sample_fit_batch_end: no fit of %d pairs is pending", pairs);
+    if (ctx->fit_copy_bytes) {   // no plan call took the download with it: queue it behind the fit kernels now
+        VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, ctx->d_fit.ptr, ctx->fit_copy_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VSTAB_HIP(hipEventRecord(ctx->ev_fit_done, ctx->stream));
+        ctx->fit_copy_bytes = 0;
+    }
     VSTAB_HIP(hipEventSynchronize(ctx->ev_fit_done));
     memcpy(results, ctx->h_fit.ptr, sizeof(vstab_fit_record) * (size_t)pairs * 3);
     ctx->fit_pairs_pending = 0;

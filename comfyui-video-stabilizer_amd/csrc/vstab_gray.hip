@@ -9,6 +9,7 @@
 // fma(b, 0.114, fma(g, 0.587, r*0.299)) and an unfused scalar tail for the last (w % 8) pixels
 // of a row; then v = gray*255 (f32), clip to [0,255], truncate.
 #include "vstab_internal.h"
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(1024) void gray_area_int_kernel(const float* __rest
 }
 
 // per-frame maximum of the per-row maxima (NaN wins, as in numpy): one workgroup per frame
-__global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict__ row_max, float* __restrict__ frame_max, int rows)
+// host_max / host_done (optional): the same value into coherent host memory, then one system-scope count per frame
+__global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict__ row_max, float* __restrict__ frame_max, int rows,
+                                                        float* host_max, unsigned* host_done)
 {
     __shared__ float s_max[4];
     __shared__ int s_nan[4];
@@ -137,7 +140,12 @@ __global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
-        frame_max[blockIdx.x] = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
+        const float v = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
+        frame_max[blockIdx.x] = v;
+        if (host_max != nullptr) {
+            __hip_atomic_store(host_max + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(host_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the value first, then the count
+        }
     }
 }
 
@@ -370,7 +378,20 @@ static int gray_run(vstab_ctx* ctx, const float* frames, int n, int src_h, int s
     }
 #undef LAUNCH_GRAY
     if (frame_max) {
-        hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, range_rows);
+        // the host's copy of the maxima: written by the kernel itself into coherent host memory (no copy, no event on the stream)
+        if (ctx->h_peaks_cap < n) {
+            if (ctx->h_peaks) { VSTAB_HIP(hipStreamSynchronize(st)); VSTAB_HIP(hipHostFree(ctx->h_peaks)); ctx->h_peaks = nullptr; ctx->h_peaks_cap = 0; }
+            const int cap = std::max(1024, n);
+            void* hp = nullptr;
+            VSTAB_HIP(hipHostMalloc(&hp, sizeof(float) * (size_t)cap, hipHostMallocMapped | hipHostMallocCoherent));
+            void* dp = nullptr;
+            VSTAB_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+            ctx->h_peaks = static_cast<float*>(hp); ctx->d_peaks_mirror = static_cast<float*>(dp); ctx->h_peaks_cap = cap;
+        }
+        ctx->peaks_target += (unsigned)n;
+        ctx->peaks_frames = n;
+        hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, range_rows, ctx->d_peaks_mirror,
+                           reinterpret_cast<unsigned*>(ctx->d_status) + VSTAB_PEAKS_DONE_WORD);
         VSTAB_HIP(hipGetLastError());
     }
     return 0;
@@ -401,6 +422,29 @@ extern "C" int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, i
     return gray_run(ctx, frames, n, src_h, src_w, work_h, work_w, gray, frame_max);
 }
 
+// The maxima of the latest vstab_gray_downscale_range call, on the host: waits for that call's frame_max_kernel only (a
+// count in coherent host memory the kernel bumps once per frame), not for anything queued behind it.
+extern "C" int vstab_last_frame_peaks(vstab_ctx* ctx, int n, float* out)
+{
+    VSTAB_REQUIRE(ctx != nullptr && out != nullptr, "vstab_last_frame_peaks: NULL argument");
+    VSTAB_REQUIRE(ctx->h_peaks != nullptr && n == ctx->peaks_frames, "vstab_last_frame_peaks: no range pass over %d frames is pending", n);
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(ctx->h_status) + VSTAB_PEAKS_DONE_WORD;
+    const unsigned target = ctx->peaks_target;
+    // the gray pass of a 256 x 1080p clip takes ~1 ms; should the count never arrive (a lost launch), a stream
+    // synchronisation after ~2 s turns the wait into the runtime's own error report
+    for (long spins = 0; (int)(*done - target) < 0; spins++) {
+        if (spins > 20000000L) {
+            VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+            VSTAB_REQUIRE((int)(*done - target) >= 0, "vstab_last_frame_peaks: the range pass finished without reporting its %d frames", n);
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    memcpy(out, ctx->h_peaks, sizeof(float) * (size_t)n);
+    return 0;
+}
+
 extern "C" int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, float* frame_max)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_frame_range: ctx is NULL");
@@ -421,7 +465,7 @@ extern "C" int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int
     KernelTimer timer(ctx, "range");
     if (vec) hipLaunchKernelGGL(row_max_kernel<true>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
     else hipLaunchKernelGGL(row_max_kernel<false>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
-    hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces);
+    hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces, (float*)nullptr, (unsigned*)nullptr);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }

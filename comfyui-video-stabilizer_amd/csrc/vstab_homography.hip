@@ -58,132 +58,164 @@ __device__ __forceinline__ void load_point(const float* __restrict__ F, int gw, 
 // JacobiImpl_ of OpenCV (core/src/lapack.cpp) for a symmetric n x n fp64 matrix; eigenvalues sorted descending,
 // eigenvectors are the rows of V.
 // Workspace of one eigen-solve / one 8x8 elimination.  It lives in LDS: the solvers index their matrices with
-// run-time pivots, which would otherwise put them in scratch memory (a phase profile showed the 16 concurrent
-// 4-point solves taking 1.1 ms and the single-lane refit 0.4 ms that way).  181 doubles per slot: consecutive
-// slots start 10 banks apart, so the lanes of a batch do not collide on equal indices.
+// run-time pivots, which would otherwise put them in scratch memory, and since round 5 the sixteen lanes of a group
+// share one solve through it.
 struct JacWs {
     double A[81];
     double V[81];
     double W[9];
     int indR[9], indC[9];
+    double norm[8];   // cmx, cmy, cMx, cMy, smx, smy, sMx, sMy of the solve in progress (written by the group's lane 0)
+    int go, pad_;     // lane 0's verdict: the normalisation is not degenerate, the group runs the eigen-solve
     double pad;
 };
 
-__device__ void jacobi_eigen(double* A, int n, double* W, double* V, int* indR, int* indC)
+// Sixteen lanes of one wavefront (an aligned group: lane g = threadIdx.x & 15) work on one JacWs together.  They run in
+// lockstep and exchange everything through LDS, whose operations a wavefront issues and completes in order: between a phase
+// that writes and a phase that reads only the COMPILER has to be kept from moving accesses across -- no s_barrier, so
+// groups of one wavefront may sit in different iterations (or have left the loop) without harm.
+__device__ __forceinline__ void group_sync()
 {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The eigen-solve by a group of 16 lanes (n = 9; the serial form is oracle/vo_fit.c's jacobi_eigen).  OpenCV's algorithm is
+// sequential in its ROTATIONS; inside one
+// rotation the sixteen element pairs it turns -- seven of A (the rows / columns k and l without their crossing), nine of V
+// (rows k and l) -- are independent, and so are the four index scans that follow: one pair, one scan per lane, the same
+// fp64 operations on the same values as the serial loop, so the same bits.  The pivot search and c / s / t are computed by every lane redundantly (LDS broadcast reads).  A phase
+// profile had the 16 serial solves of a batch at 535-553 us (one lane each, diverging) and the refit's at 269 us of the
+// kernel's 1.17 ms per pair (profiles/r05_homography.md).
+__device__ void jacobi_eigen_g16(JacWs& ws, int g)
+{
+    constexpr int n = 9;
     const double eps = 2.220446049250313e-16;
-    int i, j, k, m;
-    double mv;
-    for (i = 0; i < n; i++) {
-        for (j = 0; j < n; j++) V[i * n + j] = 0;
-        V[i * n + i] = 1;
-    }
-    for (k = 0; k < n; k++) {
+    double* A = ws.A; double* V = ws.V; double* W = ws.W;
+    int* indR = ws.indR; int* indC = ws.indC;
+    for (int e = g; e < n * n; e += 16) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+    if (g < n) {
+        const int k = g;
         W[k] = A[(n + 1) * k];
         if (k < n - 1) {
-            for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) {
-                double val = fabs(A[n * k + i]);
-                if (mv < val) mv = val, m = i;
-            }
+            int m = k + 1;
+            double mv = fabs(A[n * k + m]);
+            for (int i = k + 2; i < n; i++) { const double val = fabs(A[n * k + i]); if (mv < val) mv = val, m = i; }
             indR[k] = m;
         }
         if (k > 0) {
-            for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) {
-                double val = fabs(A[n * i + k]);
-                if (mv < val) mv = val, m = i;
-            }
+            int m = 0;
+            double mv = fabs(A[k]);
+            for (int i = 1; i < k; i++) { const double val = fabs(A[n * i + k]); if (mv < val) mv = val, m = i; }
             indC[k] = m;
         }
     }
+    group_sync();
     const int maxIters = n * n * 30;
-    if (n > 1)
-        for (int iters = 0; iters < maxIters; iters++) {
-            for (k = 0, mv = fabs(A[indR[0]]), i = 1; i < n - 1; i++) {
-                double val = fabs(A[n * i + indR[i]]);
-                if (mv < val) mv = val, k = i;
+    for (int iters = 0; iters < maxIters; iters++) {
+        int k = 0;
+        double mv = fabs(A[indR[0]]);
+        for (int i = 1; i < n - 1; i++) { const double val = fabs(A[n * i + indR[i]]); if (mv < val) mv = val, k = i; }
+        int l = indR[k];
+        for (int i = 1; i < n; i++) { const double val = fabs(A[n * indC[i] + i]); if (mv < val) mv = val, k = indC[i], l = i; }
+        const double p = A[n * k + l];
+        if (fabs(p) <= eps) break;                       // uniform over the group
+        const double y = (W[l] - W[k]) * 0.5;
+        double t = fabs(y) + hypot(p, y);
+        double sn = hypot(p, t);
+        const double c = t / sn;
+        sn = p / sn;
+        t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+        group_sync();                                    // every lane has read A[k][l], W[k], W[l] and the index tables
+        if (g == 0) { A[n * k + l] = 0; W[k] -= t; W[l] += t; }
+        {
+            double *e0, *e1;
+            if (g < n - 2) {                             // the i-th index of 0 .. n-1 that is neither k nor l (k < l always)
+                int i = g;
+                if (i >= k) i++;
+                if (i >= l) i++;
+                if (i < k) { e0 = &A[n * i + k]; e1 = &A[n * i + l]; }
+                else if (i < l) { e0 = &A[n * k + i]; e1 = &A[n * i + l]; }
+                else { e0 = &A[n * k + i]; e1 = &A[n * l + i]; }
+            } else {
+                const int i = g - (n - 2);
+                e0 = &V[n * k + i]; e1 = &V[n * l + i];
             }
-            int l = indR[k];
-            for (i = 1; i < n; i++) {
-                double val = fabs(A[n * indC[i] + i]);
-                if (mv < val) mv = val, k = indC[i], l = i;
-            }
-            double p = A[n * k + l];
-            if (fabs(p) <= eps) break;
-            double y = (W[l] - W[k]) * 0.5;
-            double t = fabs(y) + hypot(p, y);
-            double s = hypot(p, t);
-            double c = t / s;
-            s = p / s;
-            t = (p / t) * p;
-            if (y < 0) s = -s, t = -t;
-            A[n * k + l] = 0;
-            W[k] -= t;
-            W[l] += t;
-            double a0, b0;
-#define ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
-            for (i = 0; i < k; i++) ROT(A[n * i + k], A[n * i + l]);
-            for (i = k + 1; i < l; i++) ROT(A[n * k + i], A[n * i + l]);
-            for (i = l + 1; i < n; i++) ROT(A[n * k + i], A[n * l + i]);
-            for (i = 0; i < n; i++) ROT(V[n * k + i], V[n * l + i]);
-#undef ROT
-            for (j = 0; j < 2; j++) {
-                int idx = j == 0 ? k : l;
+            const double a0 = *e0, b0 = *e1;
+            *e0 = a0 * c - b0 * sn;
+            *e1 = a0 * sn + b0 * c;
+        }
+        group_sync();
+        if (g < 4) {
+            const int idx = g < 2 ? k : l;
+            if ((g & 1) == 0) {
                 if (idx < n - 1) {
-                    for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) {
-                        double val = fabs(A[n * idx + i]);
-                        if (mv < val) mv = val, m = i;
-                    }
+                    int m = idx + 1;
+                    double mx = fabs(A[n * idx + m]);
+                    for (int i = idx + 2; i < n; i++) { const double val = fabs(A[n * idx + i]); if (mx < val) mx = val, m = i; }
                     indR[idx] = m;
                 }
-                if (idx > 0) {
-                    for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) {
-                        double val = fabs(A[n * i + idx]);
-                        if (mv < val) mv = val, m = i;
-                    }
-                    indC[idx] = m;
-                }
+            } else if (idx > 0) {
+                int m = 0;
+                double mx = fabs(A[idx]);
+                for (int i = 1; i < idx; i++) { const double val = fabs(A[n * i + idx]); if (mx < val) mx = val, m = i; }
+                indC[idx] = m;
             }
         }
-    for (k = 0; k < n - 1; k++) {
-        m = k;
-        for (i = k + 1; i < n; i++)
+        group_sync();
+    }
+    // eigenvalues descending, the rows of V with them (selection sort: n - 1 sequential steps, each swap spread over lanes)
+    for (int k = 0; k < n - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < n; i++)
             if (W[m] < W[i]) m = i;
+        group_sync();
         if (k != m) {
-            double tw = W[m]; W[m] = W[k]; W[k] = tw;
-            for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+            if (g < n) { const double tv = V[n * m + g]; V[n * m + g] = V[n * k + g]; V[n * k + g] = tv; }
+            else if (g == n) { const double tw = W[m]; W[m] = W[k]; W[k] = tw; }
         }
+        group_sync();
     }
 }
 
 // H from the normalisation parameters and LtL (HomographyEstimatorCallback::runKernel after the accumulation)
-__device__ void homography_from_ltl(JacWs& ws, double cmx, double cmy, double cMx, double cMy, double smx, double smy,
-                                    double sMx, double sMy, double* H)
+// ws.A holds the upper triangle of LtL, ws.norm the normalisation: mirror, eigen-solve (the group), compose H (lane 0)
+__device__ void homography_from_ltl_g16(JacWs& ws, int g, double* H /* lane 0's result */)
 {
-    double* LtL = ws.A;   // upper triangle filled by the caller
-    for (int j = 0; j < 9; j++)
-        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi_eigen(LtL, 9, ws.W, ws.V, ws.indR, ws.indC);
-    const double* H0 = ws.V + 72;
-    const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
-    const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
-    double T[9], R[9];
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += invHnorm[r * 3 + k] * H0[k * 3 + c];
-            T[r * 3 + c] = s;
-        }
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += T[r * 3 + k] * Hnorm2[k * 3 + c];
-            R[r * 3 + c] = s;
-        }
-    const double sc = 1. / R[8];
-    for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
+    double* LtL = ws.A;
+    for (int e = g; e < 81; e += 16) {
+        const int j = e / 9, k = e - j * 9;
+        if (k < j) LtL[j * 9 + k] = LtL[k * 9 + j];
+    }
+    group_sync();
+    jacobi_eigen_g16(ws, g);
+    if (g == 0) {
+        const double cmx = ws.norm[0], cmy = ws.norm[1], cMx = ws.norm[2], cMy = ws.norm[3];
+        const double smx = ws.norm[4], smy = ws.norm[5], sMx = ws.norm[6], sMy = ws.norm[7];
+        const double* H0 = ws.V + 72;
+        const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+        const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+        double T[9], R[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += invHnorm[r * 3 + k] * H0[k * 3 + c];
+                T[r * 3 + c] = s;
+            }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += T[r * 3 + k] * Hnorm2[k * 3 + c];
+                R[r * 3 + c] = s;
+            }
+        const double sc = 1. / R[8];
+        for (int i = 0; i < 9; i++) H[i] = R[i] * sc;
+    }
 }
 
-__device__ bool homography_4pt(JacWs& ws, const float* M, const float* m, double* H)
+// lane 0 of a group: normalisation + LtL of a 4-point sample into ws (runKernel's accumulation); false: degenerate
+__device__ bool homography_4pt_setup(JacWs& ws, const float* M, const float* m)
 {
     double* LtL = ws.A;
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
@@ -206,7 +238,8 @@ __device__ bool homography_4pt(JacWs& ws, const float* M, const float* m, double
         for (int j = 0; j < 9; j++)
             for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
     }
-    homography_from_ltl(ws, cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
+    ws.norm[0] = cmx; ws.norm[1] = cmy; ws.norm[2] = cMx; ws.norm[3] = cMy;
+    ws.norm[4] = smx; ws.norm[5] = smy; ws.norm[6] = sMx; ws.norm[7] = sMy;
     return true;
 }
 
@@ -249,6 +282,25 @@ __device__ __forceinline__ T block_sum(T v, T* scratch)
     return total;
 }
 
+// N block sums at once: the same wavefront shuffle tree and the same ((w0 + w1) + w2) + w3 order as N calls of block_sum
+// -- the same bits -- behind two barriers instead of 3 N (the normal equations of an LM step are 44 sums: 132 barriers).
+// part: LDS [HT / 64][N]; out: LDS [N], valid for every thread on return.
+template <int N>
+__device__ __forceinline__ void block_sum_many(const double (&acc)[N], double* part, double* out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double v = acc[i];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s);
+        if (lane == 0) part[wave * N + i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += HT) out[i] = ((part[i] + part[N + i]) + part[2 * N + i]) + part[3 * N + i];
+    __syncthreads();
+}
+
 // solve the symmetric n x n system A x = b (n <= 8) by Gaussian elimination with partial pivoting
 __device__ bool solve_sym(double (*A)[9] /* 8 rows of LDS workspace */, const double* A_in, const double* b, int n, double* x)
 {
@@ -274,7 +326,18 @@ __device__ bool solve_sym(double (*A)[9] /* 8 rows of LDS workspace */, const do
     return true;
 }
 
+#ifdef VSTAB_HOMOGRAPHY_TRACE   // developer build: per-phase time of one workgroup (tools/homography_phases.py)
+static long long* g_h_dbg = nullptr;
+extern "C" void vstab_homography_dbg(long long* p) { g_h_dbg = p; }
+#define H_MARK(i) do { if (prof_) { const long long now_ = wall_clock64(); a.dbg[i] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define H_MARK(i)
+#endif
+
 struct HArgs {
+#ifdef VSTAB_HOMOGRAPHY_TRACE
+    long long* dbg;
+#endif
     const float* grid_flow;
     const int* vmap;
     vstab_fit_record* out;
@@ -285,7 +348,8 @@ struct HArgs {
 // residuals + (optionally) the normal equations of HomographyRefineCallback for parameters h[8] over the inliers
 // (inlier test against Hbest in f32, threshold thr).  Returns S = |r|^2; JtJ (36 upper entries) / Jtr (8) if wanted.
 __device__ double lm_accumulate(const HArgs& a, const float* F, const int* vmap, int nv, const float* Hbf, float thr, const double* h,
-                                bool want_jac, double* JtJ /*64*/, double* Jtr /*8*/, double* rinf, double* s_red)
+                                bool want_jac, double* JtJ /*64*/, double* Jtr /*8*/, double* rinf, double* s_red, double* s_part /*[4][45]*/,
+                                double* s_sum /*[45]*/)
 {
     double acc[45];
     for (int i = 0; i < 45; i++) acc[i] = 0;
@@ -323,13 +387,19 @@ __device__ double lm_accumulate(const HArgs& a, const float* F, const int* vmap,
     *rinf = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     __syncthreads();
     if (want_jac) {
-        int idx = 0;
-        for (int p = 0; p < 8; p++)
-            for (int q = p; q < 8; q++) {
-                const double v = block_sum(acc[idx++], s_red);
-                JtJ[p * 8 + q] = v; JtJ[q * 8 + p] = v;
+        block_sum_many<45>(acc, s_part, s_sum);   // (entry 44 is unused padding of the accumulator array)
+        if (threadIdx.x < 44) {
+            const int i = threadIdx.x;
+            if (i < 36) {
+                int p = 0, base = 0;
+                while (i >= base + (8 - p)) { base += 8 - p; p++; }
+                const int q = p + (i - base);
+                JtJ[p * 8 + q] = s_sum[i]; JtJ[q * 8 + p] = s_sum[i];
+            } else {
+                Jtr[i - 36] = s_sum[i];
             }
-        for (int p = 0; p < 8; p++) Jtr[p] = block_sum(acc[36 + p], s_red);
+        }
+        __syncthreads();
     }
     return S;
 }
@@ -342,6 +412,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
     __shared__ int s_idx[HBATCH][4];
     __shared__ int s_cnt[HBATCH];
     __shared__ double s_red[8];
+    __shared__ double s_part[4 * 45], s_sum[45];
     __shared__ int s_redi[8];
     __shared__ double s_best[9];
     __shared__ double s_A[64], s_v[8], s_x[8], s_d[8];
@@ -352,6 +423,10 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
     double (*elim)[9] = reinterpret_cast<double (*)[9]>(s_ws[1].A);   // 8x9 elimination tableau of the LM steps (lane 0 only)
 
     const int pair = blockIdx.x, tid = threadIdx.x;
+#ifdef VSTAB_HOMOGRAPHY_TRACE
+    long long tprev_ = wall_clock64();
+    const bool prof_ = a.dbg && blockIdx.x == 7 && threadIdx.x == 0;
+#endif
     const bool points = a.gw == 0;
     const float* __restrict__ F = a.grid_flow + (size_t)pair * a.cap * (points ? 4 : 2);
     const int* __restrict__ vmap = a.vmap + (size_t)pair * a.cap;
@@ -395,21 +470,33 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             s_rng = r;
         }
         __syncthreads();
-        if (tid < HBATCH) {
-            s_ok[tid] = 0;
-            s_cnt[tid] = 0;
-            if (s_idx[tid][0] >= 0) {
-                float ms1[8], ms2[8];
-                for (int i = 0; i < 4; i++) load_point(F, a.gw, a.step, vmap[s_idx[tid][i]], ms1[i * 2], ms1[i * 2 + 1], ms2[i * 2], ms2[i * 2 + 1]);
+        H_MARK(0);
+        {   // the batch's 16 minimal solves: one per group of 16 lanes (HT = 16 x 16)
+            const int grp = tid >> 4, g = tid & 15;
+            JacWs& ws = s_ws[grp];
+            if (g == 0) {
+                s_ok[grp] = 0;
+                s_cnt[grp] = 0;
+                ws.go = 0;
+                if (s_idx[grp][0] >= 0) {
+                    float ms1[8], ms2[8];
+                    for (int i = 0; i < 4; i++) load_point(F, a.gw, a.step, vmap[s_idx[grp][i]], ms1[i * 2], ms1[i * 2 + 1], ms2[i * 2], ms2[i * 2 + 1]);
+                    ws.go = homography_4pt_setup(ws, ms1, ms2) ? 1 : 0;
+                }
+            }
+            group_sync();
+            if (ws.go) {
                 double H[9];
-                if (homography_4pt(s_ws[tid], ms1, ms2, H)) {
-                    for (int k = 0; k < 9; k++) s_model[tid][k] = H[k];
-                    for (int k = 0; k < 8; k++) s_modelf[tid][k] = (float)H[k];
-                    s_ok[tid] = 1;
+                homography_from_ltl_g16(ws, g, H);
+                if (g == 0) {
+                    for (int k = 0; k < 9; k++) s_model[grp][k] = H[k];
+                    for (int k = 0; k < 8; k++) s_modelf[grp][k] = (float)H[k];
+                    s_ok[grp] = 1;
                 }
             }
         }
         __syncthreads();
+        H_MARK(1);
         int cnt[HBATCH];
 #pragma unroll
         for (int c = 0; c < HBATCH; c++) cnt[c] = 0;
@@ -432,6 +519,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[c], v);
         }
         __syncthreads();
+        H_MARK(2);
         if (tid == 0) {
             int niters = s_ctl[1], iter = s_ctl[2], maxGood = s_ctl[3];
             bool stop = false;
@@ -449,6 +537,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             s_ctl[0] = (stop || iter >= niters) ? 1 : 0;
         }
         __syncthreads();
+        H_MARK(3);
         if (s_ctl[0]) break;
     }
     const int maxGood = s_ctl[3];
@@ -503,30 +592,39 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             for (int j = 0; j < 9; j++)
                 for (int q = j; q < 9; q++) acc[idx++] += Lx[j] * Lx[q] + Ly[j] * Ly[q];
         }
+        H_MARK(4);
         double* s_LtL = s_ws[0].A;   // the refit reuses slot 0 (the batch solves are finished)
-        int idx = 0;
-        for (int j = 0; j < 9; j++)
-            for (int q = j; q < 9; q++) {
-                const double v = block_sum(acc[idx++], s_red);
-                if (tid == 0) s_LtL[j * 9 + q] = v;
-            }
+        block_sum_many<45>(acc, s_part, s_sum);
+        if (tid < 45) {
+            int j = 0, base = 0;
+            while (tid >= base + (9 - j)) { base += 9 - j; j++; }
+            s_LtL[j * 9 + j + (tid - base)] = s_sum[tid];
+        }
         __syncthreads();
-        if (tid == 0) {
+        H_MARK(5);
+        if (tid < 16) {   // the first group of 16 lanes (one wavefront's DPP row 0)
+            if (tid == 0) {
+                double* nm = s_ws[0].norm;
+                nm[0] = cmx; nm[1] = cmy; nm[2] = cMx; nm[3] = cMy; nm[4] = smx; nm[5] = smy; nm[6] = sMx; nm[7] = sMy;
+            }
+            group_sync();
             double H[9];
-            homography_from_ltl(s_ws[0], cmx, cmy, cMx, cMy, smx, smy, sMx, sMy, H);
-            for (int i = 0; i < 9; i++) s_best[i] = H[i];
+            homography_from_ltl_g16(s_ws[0], tid, H);
+            if (tid == 0) for (int i = 0; i < 9; i++) s_best[i] = H[i];
         }
         __syncthreads();
     }
+    H_MARK(6);
     // ---- Levenberg-Marquardt, 10 iterations (LMSolverImpl::run, eps = FLT_EPSILON), parameters h[0..7]
     double x[8];
     for (int i = 0; i < 8; i++) x[i] = s_best[i];
     double rinf;
-    double S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red);
+    double S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red, s_part, s_sum);
     __shared__ double s_D[8];
     if (tid == 0) { for (int i = 0; i < 8; i++) s_D[i] = s_A[i * 8 + i]; s_lm[0] = 1.0; s_lm[1] = 0.75; }
     __syncthreads();
     const double Rlo = 0.25, Rhi = 0.75;
+    H_MARK(7);
     for (int iter = 0; iter < 10; iter++) {
         if (tid == 0) {
             double Ap[64];
@@ -537,10 +635,12 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             for (int i = 0; i < 8; i++) { s_d[i] = d[i]; s_x[i] = x[i] - d[i]; }
         }
         __syncthreads();
+        H_MARK(8);
         double xd[8];
         for (int i = 0; i < 8; i++) xd[i] = s_x[i];
         double rinf_d;
-        const double Sd = lm_accumulate(a, F, vmap, nv, Hbf, thr, xd, false, nullptr, nullptr, &rinf_d, s_red);
+        const double Sd = lm_accumulate(a, F, vmap, nv, Hbf, thr, xd, false, nullptr, nullptr, &rinf_d, s_red, s_part, s_sum);
+        H_MARK(9);
         if (tid == 0) {
             double dS = 0, tdv = 0;
             for (int i = 0; i < 8; i++) {
@@ -573,6 +673,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             s_lm[3] = (Sd < S) ? 1.0 : 0.0;
         }
         __syncthreads();
+        H_MARK(10);
         const bool accept = s_lm[3] != 0.0;
         double dinf = 0;
         for (int i = 0; i < 8; i++) dinf = fmax(dinf, fabs(s_d[i]));
@@ -580,9 +681,13 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
             S = Sd;
             for (int i = 0; i < 8; i++) x[i] = xd[i];
             __syncthreads();
-            S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red);
+            S = lm_accumulate(a, F, vmap, nv, Hbf, thr, x, true, s_A, s_v, &rinf, s_red, s_part, s_sum);
         }
         __syncthreads();
+        H_MARK(11);
+#ifdef VSTAB_HOMOGRAPHY_TRACE
+        if (prof_) a.dbg[14] += 1;
+#endif
         if (!(iter + 1 < 10 && dinf >= 1.1920928955078125e-07 && rinf >= 1.1920928955078125e-07)) break;
     }
     // ---- record (flow.py:171-175: confidence = inliers/valid, residual uses the affine part of H only)
@@ -594,6 +699,7 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
         res += fabs(X * x[0] + Y * x[1] + x[2] - (double)cx) + fabs(X * x[3] + Y * x[4] + x[5] - (double)cy);
     }
     res = block_sum(res, s_red);
+    H_MARK(12);
     if (tid == 0) {
         out->computed = 1;
         out->confidence = (double)maxGood / (double)nv;
@@ -611,7 +717,11 @@ __global__ __launch_bounds__(HT) void homography_kernel(HArgs a)
 int vstab_fit_homography(vstab_ctx* ctx, const float* grid_flow, const int* vmap, int pairs, int gh, int gw, int step,
                          int cap, vstab_fit_record* d_out)
 {
-    HArgs a{grid_flow, vmap, d_out, pairs, gh, gw, step, cap};
+    HArgs a{
+#ifdef VSTAB_HOMOGRAPHY_TRACE
+        g_h_dbg,
+#endif
+        grid_flow, vmap, d_out, pairs, gh, gw, step, cap};
     hipLaunchKernelGGL(homography_kernel, dim3((unsigned)pairs), dim3(HT), 0, ctx->stream, a);
     VSTAB_HIP(hipGetLastError());
     return 0;

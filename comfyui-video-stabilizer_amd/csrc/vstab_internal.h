@@ -52,6 +52,7 @@ struct vstab_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     bool timing_detail = false;                 // vstab_set_timing(ctx, 2): also events around the stages INSIDE a DIS call
+    bool timing_warp_only = false;              // vstab_set_timing(ctx, 3): events around the warp launches only (the roofline kernel)
     bool dis_first_pair_is_clip_start = true;   // see vstab_dis_set_clip_start
     std::map<std::string, EventPair> timers;
     // staging for small per-call parameter tables (pinned host + device mirror)
@@ -63,6 +64,14 @@ struct vstab_ctx {
     // bit into it through d_status; the host reads h_status after any stream synchronisation at no cost.
     volatile int* h_status = nullptr;
     int* d_status = nullptr;
+    // F0's per-frame maxima as the gray pass reports them, mirrored into coherent host memory by the kernel that forms them
+    // (frame_max_kernel) -- no copy and no event on the stream (those cost the stream ~25 us between the gray pass and the
+    // pyramid, profiles/r05_dis_small_steps.md).  h_status[VSTAB_PEAKS_DONE_WORD] counts the frames written since the context
+    // was created; peaks_target is the count at which the latest range pass is complete (vstab_last_frame_peaks polls it).
+    float* h_peaks = nullptr;       // host pointer
+    float* d_peaks_mirror = nullptr;   // the same memory as the device sees it
+    int h_peaks_cap = 0, peaks_frames = 0;
+    unsigned peaks_target = 0;
     // bulk host <-> device transfers (vstab_xfer.hip): pinned ring, its events, a copy stream
     ScratchBuf h_xfer;
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -73,6 +82,14 @@ struct vstab_ctx {
     ScratchBuf d_plan, h_plan;
     hipEvent_t ev_fit_done = nullptr, ev_plan_done = nullptr;
     int fit_pairs_pending = 0, plan_frames = 0, plan_params = 0;
+    // The downloads behind the speculative plan (fit records, plan results) run on a stream of their own, behind ONE event
+    // recorded after plan_kernel: a copy queued on the call's stream sat between fit -> plan -> warp as two engine hand-overs
+    // (19 + 27 us of idle GPU per C2 step, profiles/r05_dis_small_steps.md).  fit_copy_bytes > 0: the fit records'
+    // download has not been issued yet (vstab_flow_plan_device issues it on the side stream, vstab_sample_fit_batch_end on
+    // the call's stream if no plan call came in between).
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_side = nullptr;
+    size_t fit_copy_bytes = 0;
     // DIS: the per-level image preparation (pad, gradients, structure tensor) runs on its own stream beside the
     // coarse-to-fine chain, one event per pyramid level (vstab_dis.hip)
     hipStream_t prep_stream = nullptr;
@@ -80,6 +97,7 @@ struct vstab_ctx {
     hipEvent_t ev_pyramid = nullptr;
 };
 
+enum { VSTAB_PEAKS_DONE_WORD = 4 };      // index into h_status / d_status (the status word itself is [0])
 enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired
 
 // Call after a host synchronisation of ctx->stream: turns a device-side failure report into a non-zero return
@@ -97,7 +115,9 @@ struct KernelTimer {
     vstab_ctx* ctx;
     EventPair* ev = nullptr;
     KernelTimer(vstab_ctx* c, const char* k) : ctx(c) {
-        if (ctx->timing) {
+        // (level 3: an event pair costs the stream ~10 us -- 0.05-0.1 ms over the four stages of a C2 step, measured -- so a
+        // timed loop keeps them around the one kernel whose per-launch time it reports, profiles/r05_dis_small_steps.md)
+        if (ctx->timing && (!ctx->timing_warp_only || strncmp(k, "warp", 4) == 0)) {
             ev = vstab_timer_slot(ctx, k);
             // the previous launch of this kind finished long ago (every pipeline pass synchronises with the host
             // between two launches of the same kind), so folding it costs no wait

@@ -334,6 +334,9 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     ctx->h_plan.pinned_host = true;
     if (ctx->h_plan.reserve(L.xf)) return 1;   // everything but the warp table comes back
     if (!ctx->ev_plan_done) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_plan_done, hipEventDisableTiming));
+    // a previous plan whose results nobody collected (a discarded speculative run): its download from d_plan, on the side
+    // stream, has to be over before this call's kernel writes d_plan again (a host wait on an event long past: no stream cost)
+    else if (ctx->plan_frames > 0) VSTAB_HIP(hipEventSynchronize(ctx->ev_plan_done));
     char* base = static_cast<char*>(ctx->d_plan.ptr);
     PlanArgs a{};
     a.rec = d_records; a.pairs = pairs; a.mode = requested_mode;
@@ -370,9 +373,22 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
         VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_T), lds, ctx->stream, a);
     VSTAB_HIP(hipGetLastError());
-    // the verification copy is queued BEFORE the warp that follows on this stream, so the host has it while the warp runs
-    VSTAB_HIP(hipMemcpyAsync(ctx->h_plan.ptr, base, L.xf, hipMemcpyDeviceToHost, ctx->stream));
-    VSTAB_HIP(hipEventRecord(ctx->ev_plan_done, ctx->stream));
+    // The host's copies -- this rank's fit records, if their download is still owed, and everything of the plan but the warp
+    // table -- go out on a stream of their own behind ONE event recorded here: the warp that follows on the call's stream
+    // starts without waiting for a copy engine, and the host has both while the warp runs.
+    if (!ctx->side_stream) {
+        VSTAB_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    }
+    VSTAB_HIP(hipEventRecord(ctx->ev_side, ctx->stream));
+    VSTAB_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_side, 0));
+    if (ctx->fit_copy_bytes) {
+        VSTAB_HIP(hipMemcpyAsync(ctx->h_fit.ptr, ctx->d_fit.ptr, ctx->fit_copy_bytes, hipMemcpyDeviceToHost, ctx->side_stream));
+        VSTAB_HIP(hipEventRecord(ctx->ev_fit_done, ctx->side_stream));
+        ctx->fit_copy_bytes = 0;
+    }
+    VSTAB_HIP(hipMemcpyAsync(ctx->h_plan.ptr, base, L.xf, hipMemcpyDeviceToHost, ctx->side_stream));
+    VSTAB_HIP(hipEventRecord(ctx->ev_plan_done, ctx->side_stream));
     ctx->plan_frames = frames; ctx->plan_params = p;
     return 0;
 }

@@ -13,6 +13,7 @@
 //   * blockIdx is remapped so that the 8 XCDs (private L2 each) own contiguous runs of tiles
 //   * padding-pixel count: wave shuffle reduction -> LDS -> one atomic per block, only if non-zero
 #include "vstab_internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -453,6 +454,7 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
     // ---- the source window this tile can touch, over all samples
     bool fast = G::FAST && a.blur_fast != 0;
     bool inside = false;   // the staged window lies inside the source: no tap of the tile meets the border
+    bool inside_persp = false;   // ... and some sample of the frame has a perspective row (its own copy of the interior loop)
     int ox = 0, oy = 0, fw = 0;
     if (fast) {
         bool ok = true, any_persp = false;
@@ -517,8 +519,12 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             fw = s_box[2] - s_box[0] + G::TAPS + 2;
             const int fh = s_box[3] - s_box[1] + G::TAPS + 2;
             fast = fw * fh <= G::FOOT_TEXELS;   // uniform
-            // (perspective samples and the exact sampler take the border-capable loop: it carries their coordinate forms)
-            inside = !G::EXACT && !persp && ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
+            // (the exact sampler takes the border-capable loop, which carries its coordinate form; a window that lies inside
+            // the source serves perspective samples through the interior loop too since round 5: the window bounds every
+            // tap of every pixel-sample, so no tap meets the border and the nearest-neighbour coverage pixel -- one of the
+            // two bilinear columns / rows around the sample -- lies inside as well)
+            inside = !G::EXACT && ox >= 0 && oy >= 0 && ox + fw <= a.sw && oy + fh <= a.sh;
+            inside_persp = inside && persp;
             if (fast) {
                 // stage the window: one texel (12 contiguous bytes) per lane and step -> whole cache lines per row.  A
                 // window that leaves the source (the ring of tiles along the content's edge) is filled with the border
@@ -656,6 +662,12 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
             }
         }
     } else if (active && fast) {
+        // ---- the INTERIOR loop.  Two copies, chosen per block: frames whose samples are all affine keep the loop of rounds
+        // 3-4 untouched (it sits at the 128-VGPR limit); a frame with a perspective sample (Flow in perspective mode ->
+        // Motion Apply: BASELINE C3) takes the copy that forms the general loop's per-pixel denominator -- 1 / W in fp64 per
+        // pixel-sample is the contract, W's tile-uniform part W0 is formed once per thread and sample like X0 / Y0 -- and
+        // nothing else of the border-capable loop: no bounds tests, no per-tap validity, no coverage arithmetic
+        // (C3's blur warp: see profiles/r05_c3_chain.md).
         const int xb = block_origin(x0);                 // == block_origin(x0 + TILE_TX): blur_fast
         const double dy = (double)y, dxb = (double)xb;
         // a pixel of this thread beyond the right edge (ragged last tile) re-evaluates pixel 0 instead of being skipped:
@@ -664,43 +676,56 @@ __global__ __launch_bounds__((BlurGeom<INTERP, SUBPIX>::NT)) __attribute__((amdg
 #pragma unroll
         for (int p = 0; p < TILE_PX; p++) dx1[p] = (double)((p < npx ? x0 + p * TILE_TX : x0) - xb);
         const int tap0 = (oy + G::LEAD) * fw + ox + G::LEAD;   // window index of tap (0,0) = (sy * fw + sx) - tap0
-        for (int k = 0; k < nxf; k++) {
-            const WarpXform* __restrict__ xf = xf0 + k;
-            const double m0 = xf->m[0], m3 = xf->m[3], wq = xf->wq;
-            const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
-            const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+        auto interior = [&](auto persp_tag) {
+            constexpr bool PERSP = decltype(persp_tag)::value;
+            for (int k = 0; k < nxf; k++) {
+                const WarpXform* __restrict__ xf = xf0 + k;
+                const double m0 = xf->m[0], m3 = xf->m[3];
+                const double X0 = m0 * dxb + xf->m[1] * dy + xf->m[2];
+                const double Y0 = m3 * dxb + xf->m[4] * dy + xf->m[5];
+                const bool aff = !PERSP || xf->affine != 0;            // uniform: a property of the sample
+                const double m6 = PERSP ? xf->m[6] : 0.0;
+                const double W0 = PERSP ? m6 * dxb + xf->m[7] * dy + xf->m[8] : 0.0;
 #pragma unroll
-            for (int p = 0; p < TILE_PX; p++) {
-                const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
-                const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
-                const int sx = X >> 5, sy = Y >> 5;
-                const int fx = X & 31, fy = Y & 31;
-                const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)sy, (unsigned)fw) + sx - tap0);
-                if (INTERP == VSTAB_INTERP_BICUBIC) {
-                    const f4_t cxv = reinterpret_cast<const f4_t*>(s_cub)[fx], cyv = reinterpret_cast<const f4_t*>(s_cub)[fy];
-                    const float cx[4] = {cxv.x, cxv.y, cxv.z, cxv.w}, cy[4] = {cyv.x, cyv.y, cyv.z, cyv.w};
-                    float sr = 0.f, sg = 0.f, sb = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const f4_t t0 = T[i * fw], t1 = T[i * fw + 1], t2 = T[i * fw + 2], t3 = T[i * fw + 3];
-                        const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
-                        const float tr_ = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
-                        const float tg_ = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
-                        const float tb_ = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
-                        if (i == 0) { sr = tr_; sg = tg_; sb = tb_; }
-                        else { sr += tr_; sg += tg_; sb += tb_; }
+                for (int p = 0; p < TILE_PX; p++) {
+                    const double Xn = X0 + m0 * dx1[p], Yn = Y0 + m3 * dx1[p];
+                    double wq = xf->wq;
+                    if (PERSP && !aff) {
+                        const double W = W0 + m6 * dx1[p];
+                        wq = 32.0 * ((W != 0.0) ? 1.0 / W : 0.0);
                     }
-                    acc[p][0] += sr; acc[p][1] += sg; acc[p][2] += sb;
-                    __builtin_amdgcn_sched_barrier(0);   // one pixel's 16 taps at a time: both in flight need > 128 VGPRs (spills)
-                } else {
-                    const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
-                    const f4_t w = bilinear_weights(fx, fy);
-                    acc[p][0] += t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
-                    acc[p][1] += t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
-                    acc[p][2] += t00.z * w.x + t01.z * w.y + t10.z * w.z + t11.z * w.w;
+                    const int X = round_small(Xn * wq), Y = round_small(Yn * wq);
+                    const int sx = X >> 5, sy = Y >> 5;
+                    const int fx = X & 31, fy = Y & 31;
+                    const f4_t* __restrict__ T = s_foot + ((int)__umul24((unsigned)sy, (unsigned)fw) + sx - tap0);
+                    if (INTERP == VSTAB_INTERP_BICUBIC) {
+                        const f4_t cxv = reinterpret_cast<const f4_t*>(s_cub)[fx], cyv = reinterpret_cast<const f4_t*>(s_cub)[fy];
+                        const float cx[4] = {cxv.x, cxv.y, cxv.z, cxv.w}, cy[4] = {cyv.x, cyv.y, cyv.z, cyv.w};
+                        float sr = 0.f, sg = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const f4_t t0 = T[i * fw], t1 = T[i * fw + 1], t2 = T[i * fw + 2], t3 = T[i * fw + 3];
+                            const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+                            const float tr_ = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
+                            const float tg_ = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
+                            const float tb_ = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
+                            if (i == 0) { sr = tr_; sg = tg_; sb = tb_; }
+                            else { sr += tr_; sg += tg_; sb += tb_; }
+                        }
+                        acc[p][0] += sr; acc[p][1] += sg; acc[p][2] += sb;
+                        __builtin_amdgcn_sched_barrier(0);   // one pixel's 16 taps at a time: both in flight need > 128 VGPRs (spills)
+                    } else {
+                        const f4_t t00 = T[0], t01 = T[1], t10 = T[fw], t11 = T[fw + 1];
+                        const f4_t w = bilinear_weights(fx, fy);
+                        acc[p][0] += t00.x * w.x + t01.x * w.y + t10.x * w.z + t11.x * w.w;
+                        acc[p][1] += t00.y * w.x + t01.y * w.y + t10.y * w.z + t11.y * w.w;
+                        acc[p][2] += t00.z * w.x + t01.z * w.y + t10.z * w.z + t11.z * w.w;
+                    }
                 }
             }
-        }
+        };
+        if (inside_persp) interior(std::true_type{});
+        else interior(std::false_type{});
         if (WITH_MASK) {
 #pragma unroll
             for (int p = 0; p < TILE_PX; p++) cov[p] = (float)nxf;   // every sample covered: 1.f added nxf times

@@ -147,11 +147,17 @@ def apply_value_range(batch, peaks, ctx=None):
     division on the GPU need not round the same way), a host batch with NumPy."""
     # the comparison runs on the host (no extra kernel launch in the step); peaks that were prefetched to the host
     # behind the pass that produced them (prefetch_peaks) cost no copy here
+    fetch = getattr(peaks, "_vstab_fetch", None)
     host = getattr(peaks, "_vstab_host", None)
-    if host is not None:
+    if fetch is not None:                     # the gray pass mirrored them into host memory: wait for that kernel alone
+        values = fetch()
+        if not (values > 1.5).any():          # the ComfyUI IMAGE contract (0..1): nothing to do, NumPy on 256 floats
+            return batch, "0_1"
+        big = torch.from_numpy(values > 1.5)
+    elif host is not None:
         host[1].synchronize()
         values = host[0].numpy()
-        if not (values > 1.5).any():          # the ComfyUI IMAGE contract (0..1): nothing to do, NumPy on 256 floats
+        if not (values > 1.5).any():
             return batch, "0_1"
         big = host[0] > 1.5
     else:
@@ -175,7 +181,7 @@ def prefetch_peaks(peaks):
     behind the kernel that fills it; apply_value_range then finds the values on the host (the stream has long passed
     the copy by the time the estimation's own synchronisation returns) instead of paying a blocking copy of its own
     between the estimation and the warp, where the GPU idles."""
-    if peaks.device.type == "cpu":
+    if peaks.device.type == "cpu" or hasattr(peaks, "_vstab_fetch"):   # (the gray pass's maxima reach the host by themselves)
         return peaks
     host = torch.empty(peaks.shape, dtype=peaks.dtype, pin_memory=True)
     host.copy_(peaks, non_blocking=True)

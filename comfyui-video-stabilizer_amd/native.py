@@ -94,6 +94,7 @@ def fit_table_to_dicts(table: np.ndarray):
 
 _SIGNATURES = {
     "vstab_abi_version": (C.c_int, []),
+    "vstab_last_frame_peaks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_test_hooks": (C.c_int, []),
     "vstab_last_error": (C.c_char_p, []),
     "vstab_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -321,9 +322,11 @@ class Context:
     def synchronize(self) -> None:
         _check(self.lib.vstab_synchronize(self.handle), "vstab_synchronize")
 
-    def set_timing(self, enabled: bool, detail: bool = False) -> None:
-        """detail: also bracket the stages inside a DIS call (a measurement pass of its own: see vstab.h)."""
-        _check(self.lib.vstab_set_timing(self.handle, (2 if detail else 1) if enabled else 0), "vstab_set_timing")
+    def set_timing(self, enabled: bool, detail: bool = False, warp_only: bool = False) -> None:
+        """detail: also bracket the stages inside a DIS call (a measurement pass of its own: see vstab.h).
+        warp_only: events around the warp launches only (what a timed loop keeps: an event pair costs the stream ~10 us)."""
+        level = 0 if not enabled else (3 if warp_only else (2 if detail else 1))
+        _check(self.lib.vstab_set_timing(self.handle, level), "vstab_set_timing")
 
     def dis_stage_ms(self) -> Dict[str, Any]:
         """Milliseconds of the stages of the last DIS call under set_timing(True, detail=True):
@@ -461,10 +464,19 @@ class Context:
             peaks = torch.empty((n,), dtype=torch.float32, device=self.device)
             _check(self.lib.vstab_gray_downscale_range(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray), _dev_ptr(peaks)),
                    "vstab_gray_downscale_range")
+            # the host's copy needs no transfer: the kernel mirrors the maxima into coherent host memory and this fetch waits
+            # for that kernel alone (host_math.apply_value_range uses it; valid until the next range pass of this context)
+            peaks._vstab_fetch = lambda n=n: self.last_frame_peaks(n)
             return gray, peaks
         _check(self.lib.vstab_gray_downscale(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray)),
                "vstab_gray_downscale")
         return gray
+
+    def last_frame_peaks(self, n: int) -> np.ndarray:
+        """Host copy of the per-frame maxima of the latest gray_downscale(..., want_range=True) over n frames."""
+        out = np.empty((int(n),), np.float32)
+        _check(self.lib.vstab_last_frame_peaks(self.handle, int(n), out.ctypes.data), "vstab_last_frame_peaks")
+        return out
 
     def frame_range(self, frames):
         """Per-frame maximum sample of frames [N,H,W,3] f32 on the device (NaN-propagating) -> device f32 [N]."""

@@ -64,6 +64,7 @@ int vstab_synchronize(vstab_ctx* ctx);
  * "gray", "dis", "fit", "gftt", "lk", "phase").  vstab_set_timing(ctx, 1) enables it and clears the totals;
  * vstab_set_timing(ctx, 2) also brackets the stages INSIDE a DIS call ("dis_prep", "dis_pis4_L<level>",
  * "dis_level_L<level>", "dis_final": for a measurement pass of its own, the events lengthen the chain).
+ * vstab_set_timing(ctx, 3) records events around the warp launches only ("warp", "warp_blur"): what a timed loop keeps.
  * vstab_last_kernel_ms: milliseconds of the most recent call of that kind (waits for it to finish).
  * vstab_kernel_ms_stats: sum and number of all calls of that kind since timing was enabled -- no
  * synchronisation is needed inside a timed loop, bench.py reads the totals after its closing fence
@@ -153,6 +154,11 @@ int vstab_gray_downscale(vstab_ctx* ctx, const float* frames, int n, int src_h, 
  * vstab_frame_range: the sniff alone (Motion Apply has no estimation pass), an HBM-bound read of the clip. */
 int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, int n, int src_h, int src_w,
                                int work_h, int work_w, uint8_t* gray, float* frame_max);
+/* The per-frame maxima of the latest vstab_gray_downscale_range call, on the host (n = that call's frame count): the
+ * kernel that forms them also writes them into coherent host memory, so this waits for that kernel only -- nothing is
+ * copied and no event is recorded on the stream.  The host side of `float(arr.max()) > 1.5` per frame
+ * (nodes/stabilizer_utils.py:127-131). */
+int vstab_last_frame_peaks(vstab_ctx* ctx, int n, float* out);
 int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int h, int w, float* frame_max);
 /* The rule itself, out of place: out[f] = frames[f] / 255 (IEEE float32 division, numpy's `arr /= 255.0`) where
  * frame_max[f] > 1.5, else a copy.  frames, frame_max, out: dev.  The caller's tensor is never modified. */
