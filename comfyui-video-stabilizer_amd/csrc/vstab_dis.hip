@@ -226,6 +226,14 @@ struct TailArgs {
     const uint8_t* src;   // [n][h0][w0]: the finest level
     int n, h0, w0, levels;
     TailLevel lv[TAIL_MAX_LEVELS];
+    // the COARSEST level's preparation in the same launch (it is needed at once, by the chain's first patch search): padded
+    // copy, Sobel gradients, structure tensor -- what pad_replicate / sobel / tensor_h / tensor_v_kernel do for the other
+    // levels on the second stream.  prep_ext == nullptr: not requested.
+    uint8_t* prep_ext;    // [n][h + 32][w + 32]
+    short* prep_ix;       // [n][h][w]
+    short* prep_iy;
+    float* prep_tensor;   // 5 planes of [n][hs][ws]
+    int prep_ws, prep_hs, prep_lds_off;   // patch grid of the coarsest level; byte offset of the preparation's LDS scratch
 };
 
 __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
@@ -262,6 +270,37 @@ __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
             __syncthreads();
         }
         uint8_t* D = L.dst + (size_t)f * dh * dw;
+        if (L.mode == 2 && L.kx <= 4 && L.ky <= 4 && dw <= (int)blockDim.x) {
+            // General ratio with at most four taps per axis (any halving step: ratio 2 .. 2.1): a thread keeps its COLUMN's taps
+            // in registers and walks down the rows; the sixteen candidate source bytes of an output are read together
+            // (clamped addresses) and the absent taps are skipped by selects -- the same products added in the same order as
+            // the tap loops below, without their chain of dependent LDS reads (49 -> ~20 us per 256-frame clip).
+            const int rows_par = (int)blockDim.x / dw;
+            const int x = (int)threadIdx.x % dw, ry = (int)threadIdx.x / dw;
+            if (ry < rows_par) {
+                const AreaTaps ax = s_x[x];
+                const int x0 = ax.first;
+                for (int y = ry; y < dh; y += rows_par) {
+                    const AreaTaps& ay = s_y[y];
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const unsigned char* row = cur + min(ay.first + j, sh - 1) * sw;
+                        float buf = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float v = (float)row[min(x0 + k, sw - 1)];
+                            if (k < ax.n) buf += v * ax.a[k];
+                        }
+                        const float term = ay.a[j] * buf;
+                        if (j < ay.n) sum = (j == 0) ? term : sum + term;
+                    }
+                    const int o = sat_u8_round(sum);
+                    nxt[y * dw + x] = (unsigned char)o;
+                    D[y * dw + x] = (uint8_t)o;
+                }
+            }
+        } else
         for (int t = threadIdx.x; t < dh * dw; t += blockDim.x) {
             const int y = t / dw, x = t - y * dw;
             int o;
@@ -292,6 +331,74 @@ __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
         __syncthreads();
         unsigned char* tmp = cur; cur = nxt; nxt = tmp;
         sh = dh; sw = dw;
+    }
+    if (a.prep_ext != nullptr) {
+        // `cur` = the coarsest level [sh][sw].  Same values as the per-level kernels produce (integers throughout, except the
+        // vertical running sums, which keep OpenCV's sequential f32 order exactly as tensor_v_kernel does).
+        const int h = sh, w = sw, ws = a.prep_ws, hs = a.prep_hs;
+        const int we = w + 2 * DIS_BORDER, he = h + 2 * DIS_BORDER;
+        short* lx = reinterpret_cast<short*>(tail_lds + a.prep_lds_off);
+        short* ly = lx + h * w;
+        float* laux = reinterpret_cast<float*>(tail_lds + a.prep_lds_off + ((4 * h * w + 15) & ~15));   // [5][h][ws]
+        uint8_t* E = a.prep_ext + (size_t)f * he * we;
+        for (int t = threadIdx.x; t < he * we; t += blockDim.x) {
+            const int y = t / we, x = t - y * we;
+            E[t] = cur[clampi(y - DIS_BORDER, 0, h - 1) * w + clampi(x - DIS_BORDER, 0, w - 1)];
+        }
+        short* Dx = a.prep_ix + (size_t)f * h * w;
+        short* Dy = a.prep_iy + (size_t)f * h * w;
+        for (int t = threadIdx.x; t < h * w; t += blockDim.x) {
+            const int y = t / w, x = t - y * w;
+            const unsigned char* r0 = cur + reflect101(y - 1, h) * w;
+            const unsigned char* r1 = cur + y * w;
+            const unsigned char* r2 = cur + reflect101(y + 1, h) * w;
+            const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+            const int gx = (r0[xr] + 2 * r1[xr] + r2[xr]) - (r0[xl] + 2 * r1[xl] + r2[xl]);
+            const int gy = (r2[xl] + 2 * r2[x] + r2[xr]) - (r0[xl] + 2 * r0[x] + r0[xr]);
+            Dx[t] = (short)gx; Dy[t] = (short)gy;
+            lx[t] = (short)gx; ly[t] = (short)gy;
+        }
+        __syncthreads();
+        const int aplane = h * ws;
+        for (int t = threadIdx.x; t < h * ws; t += blockDim.x) {
+            const int row = t / ws, js = t - row * ws;
+            const short* xr = lx + row * w + js * PSTR;
+            const short* yr = ly + row * w + js * PSTR;
+            int s_xx = 0, s_yy = 0, s_xy = 0, s_x = 0, s_y = 0;
+#pragma unroll
+            for (int j = 0; j < PSZ; j++) {
+                const int gx = xr[j], gy = yr[j];
+                s_xx += gx * gx; s_yy += gy * gy; s_xy += gx * gy; s_x += gx; s_y += gy;
+            }
+            laux[t] = (float)s_xx; laux[aplane + t] = (float)s_yy; laux[2 * aplane + t] = (float)s_xy;
+            laux[3 * aplane + t] = (float)s_x; laux[4 * aplane + t] = (float)s_y;
+        }
+        __syncthreads();
+        const size_t oplane = (size_t)a.n * hs * ws;
+        for (int t = threadIdx.x; t < 5 * ws; t += blockDim.x) {
+            const int k = t / ws, j = t - k * ws;
+            const float* av = laux + k * aplane + j;
+            float* o = a.prep_tensor + k * oplane + (size_t)f * hs * ws + j;
+            float ring[PSZ];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < PSZ; i++) { ring[i] = av[i * ws]; sum += ring[i]; }
+            o[0] = sum;
+            int is = 1;
+            for (int i0 = PSZ; i0 < h; i0 += PSZ) {
+                float v[PSZ];
+#pragma unroll
+                for (int q = 0; q < PSZ; q++) v[q] = (i0 + q < h) ? av[(i0 + q) * ws] : 0.f;
+#pragma unroll
+                for (int q = 0; q < PSZ; q++) {
+                    if (i0 + q < h) {
+                        sum += (v[q] - ring[q]);
+                        ring[q] = v[q];
+                        if ((q + 1) % PSTR == 0) { o[(size_t)is * ws] = sum; is++; }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -857,6 +964,27 @@ __device__ __forceinline__ void upsample_px(const float* __restrict__ sU, const 
     stf(dV, q, (r0 * b0 + r1 * b1) * mul);
 }
 
+// one sample of the final resize (cv::resize INTER_LINEAR of the finest flow, x mul) at working-size pixel (dx, dy);
+// sU / sV: the pair's finest-level planes
+__device__ __forceinline__ void final_sample_px(const float* __restrict__ sU, const float* __restrict__ sV, float* __restrict__ o2, int dx, int dy,
+                                                int sh, int sw, double scale_x, double scale_y, float mul)
+{
+    int sx, sy;
+    float fx, fy;
+    lin_coord(dx, scale_x, sw, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    lin_coord(dy, scale_y, sh, sy, fy);
+    const int sy0 = clampi(sy, 0, sh - 1), sy1 = clampi(sy + 1, 0, sh - 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const int r0i = sy0 * sw, r1i = sy1 * sw;
+    float r0 = ldf(sU, r0i + sx) * a0 + ldf(sU, r0i + sx1) * a1, r1 = ldf(sU, r1i + sx) * a0 + ldf(sU, r1i + sx1) * a1;
+    o2[0] = (r0 * b0 + r1 * b1) * mul;
+    r0 = ldf(sV, r0i + sx) * a0 + ldf(sV, r0i + sx1) * a1; r1 = ldf(sV, r1i + sx) * a0 + ldf(sV, r1i + sx1) * a1;
+    o2[1] = (r0 * b0 + r1 * b1) * mul;
+}
+
 #ifdef VSTAB_FUSED_TRACE   // developer build: per-phase time of one workgroup (tools/fused_phases.py)
 static long long* g_dis_dbg = nullptr;
 extern "C" void vstab_dis_dbg(long long* p) { g_dis_dbg = p; }
@@ -917,6 +1045,12 @@ struct LevelArgs {
     float* nextV;
     VrBufs vb;
     int P, h, w, ws, hs, nh, nw, nhs, nws;   // n*: the next finer level (image size, patch grid)
+    // finest level, fused form: the stride-`g_step` grid the fit reads (final_sample_kernel's output) is formed by the pair's
+    // own workgroup behind the merge -- one launch and two kernel boundaries less on the chain
+    float* grid_out;        // [P][g_h][g_w][2] or nullptr
+    int g_h, g_w, g_step;
+    double g_sx, g_sy;
+    float g_mul;
     int tiles_x, tiles_y;   // SOR tiling (LDS temporal blocking)
     int lds_plane;          // floats per LDS plane (max padded tile)
     int parts;              // split launches: workgroups per pair of this launch (pixel slices, or tiles)
@@ -1045,6 +1179,11 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
     const int it_lo = FUSED ? 0 : a.it, it_hi = FUSED ? VAR_ITERS : a.it + 1;
     const int tile_lo = FUSED ? 0 : part, tile_hi = FUSED ? a.tiles_x * a.tiles_y : part + 1;
     if (!FUSED && (a.it & 1)) { f2_t* tmp = dIn; dIn = dOut; dOut = tmp; }
+    // A level that is ONE tile (the coarse levels: the tile is the image, no halo) keeps its increment in LDS from one
+    // fixed-point iteration to the next in the fused form: the sweeps leave exactly the values stage 4 would write and the
+    // next stage 1 would read back, so neither runs through memory (the weights are rebuilt from the LDS values, the final
+    // merge reads them there).  Same values, same operations.
+    const bool single = FUSED && a.tiles_x * a.tiles_y == 1;
     if (FUSED || MODE == LEVEL_TILE)
     for (int it = it_lo; it < it_hi; it++) {
         for (int tile = tile_lo; tile < tile_hi; tile++) {
@@ -1064,6 +1203,30 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
             // 16 B per pixel from HBM at about the CU's share of the bandwidth; its load count is not what it waits for.)
             const int s1_dy = (int)blockDim.x / pw, s1_dx = (int)blockDim.x - s1_dy * pw;
             int py = (int)threadIdx.x / pw, px = (int)threadIdx.x - py * pw;
+            if (single && it > 0) {
+                // the increment is already in the tile (ox = oy = 0, lw = w, lh = h): only the weights are formed anew
+                for (int k = threadIdx.x; k < pn; k += blockDim.x) {
+                    const int gx = px - 1, gy = py - 1;
+                    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+                        const int q = gy * w + gx;
+                        const int li = LIDX(py, px);
+                        const int lr = (gx + 1 < w) ? LIDX(py, px + 1) : li;
+                        const int ld = (gy + 1 < h) ? LIDX(py + 1, px) : li;
+                        const f2_t d0 = *reinterpret_cast<const f2_t*>(lP + li), dr = *reinterpret_cast<const f2_t*>(lP + lr),
+                                   dd = *reinterpret_cast<const f2_t*>(lP + ld);
+                        const int qr = (gx + 1 < w) ? q + 1 : q;
+                        const int qd = (gy + 1 < h) ? q + w : q;
+                        const f2_t f0 = ld2(pUV, q), fr = ld2(pUV, qr), fd = ld2(pUV, qd);
+                        const float tu = f0.x + d0.x, tv = f0.y + d0.y;
+                        const float tur = fr.x + dr.x, tvr = fr.y + dr.y;
+                        const float tud = fd.x + dd.x, tvd = fd.y + dd.y;
+                        const float ux = tur - tu, vx = tvr - tv, uy = tud - tu, vy = tvd - tv;
+                        reinterpret_cast<float*>(lP + li)[2] = div_plain(a.alpha2, sqrt_plain(ux * ux + vx * vx + uy * uy + vy * vy + a.eps2));
+                    }
+                    px += s1_dx; py += s1_dy;
+                    if (px >= pw) { px -= pw; py++; }
+                }
+            } else
             for (int k = threadIdx.x; k < pn; k += blockDim.x) {
                 const int lx = px - 1, ly = py - 1;
                 float wv = 0.f, du = 0.f, dv = 0.f;
@@ -1227,6 +1390,7 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
             const int iw = ix1 - ix0, ih = iy1 - iy0;
             const int s4_dy = (int)blockDim.x / iw, s4_dx = (int)blockDim.x - s4_dy * iw;
             int yy = (int)threadIdx.x / iw, xx = (int)threadIdx.x - yy * iw;
+            if (!single)
             for (int k = threadIdx.x; k < iw * ih; k += blockDim.x) {
                 const int gx = ix0 + xx, gy = iy0 + yy;
                 const int li = LIDX(gy - oy + 1, gx - ox + 1);
@@ -1242,7 +1406,17 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
     }
     // mergeCheckerboard(W, tempW): W + dW of the last fixed-point iteration
     if (MODE == LEVEL_MERGE && (VAR_ITERS & 1)) dIn = b.dB;   // where iteration VAR_ITERS-1 wrote
-    if (FUSED || MODE == LEVEL_MERGE) {
+    if (single) {
+        const int hw = (w + 3) >> 1;              // the one tile's column-parity layout: padded row = w + 2 entries
+        for (int q_ = (int)threadIdx.x; q_ < npx; q_ += (int)blockDim.x) {
+            const int y = q_ / w, x = q_ - y * w;
+            const f2_t f = ld2(pUV, q_);
+            const f2_t d = *reinterpret_cast<const f2_t*>(lP + ((2 * (y + 1) + ((x + 1) & 1)) * hw + ((x + 1) >> 1)));
+            stf(Uw, q_, f.x + d.x);
+            stf(Vw, q_, f.y + d.y);
+        }
+        __syncthreads();
+    } else if (FUSED || MODE == LEVEL_MERGE) {
         for (int q_ = part * (int)blockDim.x + (int)threadIdx.x; q_ < npx; q_ += nparts * (int)blockDim.x) {
             const f2_t f = ld2(pUV, q_), d = ld2(dIn, q_);
             stf(Uw, q_, f.x + d.x);
@@ -1265,6 +1439,14 @@ __global__ __launch_bounds__(FUSED_T) VSTAB_LEVEL_ATTR void level_kernel(LevelAr
             const int is = q_ / a.nws, js = q_ - is * a.nws;
             const int dy = is * PSTR + PSZ / 2, dx = js * PSTR + PSZ / 2;
             upsample_px(U, V, nU, nV, dy * a.nw + dx, dx, dy, h, w, a.up_sx, a.up_sy, 2.0f);
+        }
+    }
+    if (FUSED && a.grid_out != nullptr) {
+        // (the merge above ends in a barrier: the pair's whole U / V plane is written)
+        float* __restrict__ go = a.grid_out + (size_t)pair * a.g_h * a.g_w * 2;
+        for (int t = (int)threadIdx.x; t < a.g_h * a.g_w; t += (int)blockDim.x) {
+            const int gy = t / a.g_w, gx = t - gy * a.g_w;
+            final_sample_px(U, V, go + 2 * t, gx * a.g_step, gy * a.g_step, h, w, a.g_sx, a.g_sy, a.g_mul);
         }
     }
 #ifdef VSTAB_FUSED_TRACE
@@ -1442,6 +1624,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     }
     // (set_timing level 2 only: events around the stages of this call, vstab_internal.h)
     auto prep_timer = std::make_unique<DetailTimer>(ctx, "dis_prep");
+    bool coarsest_prepared = false;   // pyramid_tail_kernel also formed the coarsest level's padded copy, gradients and tensor
     {
         if (launch_area(st, gray, I[FINEST], n, h, w, G[FINEST].h, G[FINEST].w)) return 1;
         // the levels above the finest: one launch (pyramid_tail_kernel) where the finest level and its successor fit one
@@ -1458,12 +1641,26 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         }
         if (tail_on && tail_levels >= 1 && tail_levels <= TAIL_MAX_LEVELS && tail_lds <= 150 * 1024) {
             TailArgs ta{};
+            {   // the coarsest level's preparation rides along where its scratch fits too
+                const LevelGeom& c = G[coarsest];
+                const size_t off = (tail_lds + 15) & ~size_t(15);
+                const size_t need = (((size_t)4 * c.h * c.w + 15) & ~size_t(15)) + sizeof(float) * 5 * (size_t)c.h * c.ws;
+                if (off + need <= 150 * 1024) {
+                    ta.prep_ext = Iext[coarsest]; ta.prep_ix = Ixs[coarsest]; ta.prep_iy = Iys[coarsest]; ta.prep_tensor = tensor[coarsest];
+                    ta.prep_ws = c.ws; ta.prep_hs = c.hs; ta.prep_lds_off = (int)off;
+                    tail_lds = off + need;
+                    coarsest_prepared = true;
+                }
+            }
             ta.src = I[FINEST]; ta.n = n; ta.h0 = G[FINEST].h; ta.w0 = G[FINEST].w; ta.levels = tail_levels;
             for (int i = FINEST + 1; i <= coarsest; i++) {
                 AreaPlan pl;
                 if (int rc = plan_area(G[i - 1].h, G[i - 1].w, G[i].h, G[i].w, pl)) return rc;
                 TailLevel& tl = ta.lv[i - FINEST - 1];
                 tl.dst = I[i]; tl.h = G[i].h; tl.w = G[i].w; tl.mode = pl.mode; tl.kx = pl.isx; tl.ky = pl.isy;
+                if (pl.mode == 2) {   // general ratio: kx / ky = the most taps an output can have along the axis (floor(scale) + 2)
+                    tl.kx = (int)std::floor(pl.scale_x) + 2; tl.ky = (int)std::floor(pl.scale_y) + 2;
+                }
                 tl.scale_x = pl.scale_x; tl.scale_y = pl.scale_y;
             }
             if (tail_lds > 64 * 1024)
@@ -1486,6 +1683,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         // first patch search does not wait for a cross-stream event (its own scratch: the other levels' `aux` is in use on
         // the second stream at the same time)
         const bool own = i == coarsest;
+        if (own && coarsest_prepared) continue;
         hipStream_t s_i = own ? st : ps;
         float* aux_i = own ? aux_c : aux;
         hipLaunchKernelGGL(pad_replicate_kernel, frame_grid((long long)(g.h + 32) * (g.w + 32), n), dim3(256), 0, s_i, I[i], Iext[i], n, g.h, g.w);
@@ -1500,6 +1698,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
 
     prep_timer.reset();
 
+    bool grid_fused = false;   // the finest level's fused launch formed the sampled grid itself
     const float zeta = 0.1f, epsilon = 0.001f, alpha = 20.0f, delta = 5.0f, gamma = 10.0f, omega = 1.6f;
     const float zeta2 = zeta * zeta, eps2 = epsilon * epsilon, gamma2 = gamma / 2, delta2 = delta / 2, alpha2 = alpha / 4;
 
@@ -1572,6 +1771,13 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         // a level that is a single tile has nothing to spread inside a pair: its ten split launches would only add
         // launch boundaries to work that is latency-bound anyway (VSTAB_DIS_SPLIT=2 splits every level regardless)
         if (split && forced != 2 && la.tiles_x * la.tiles_y == 1) split = false;
+        const bool fuse_grid = !split && i == FINEST && grid_flow != nullptr;
+        if (fuse_grid) {
+            la.grid_out = grid_flow;
+            la.g_h = (h + sample_step - 1) / sample_step; la.g_w = (w + sample_step - 1) / sample_step; la.g_step = sample_step;
+            la.g_sx = 1. / ((double)w / F.w); la.g_sy = 1. / ((double)h / F.h); la.g_mul = (float)(1 << FINEST);
+            grid_fused = true;
+        }
         if (!split) {
             if (vr_lds_bytes > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(level_kernel<LEVEL_FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vr_lds_bytes));
@@ -1602,7 +1808,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
     DetailTimer final_timer(ctx, "dis_final");
     const double fsx = 1. / ((double)w / F.w), fsy = 1. / ((double)h / F.h);
     const float mul = (float)(1 << FINEST);
-    if (grid_flow) {
+    if (grid_flow && !grid_fused) {
         const int gh = (h + sample_step - 1) / sample_step, gw = (w + sample_step - 1) / sample_step;
         hipLaunchKernelGGL(final_sample_kernel, frame_grid((long long)gh * gw, P), dim3(256), 0, st, Ul[FINEST], Vl[FINEST], grid_flow, P,
                            F.h, F.w, gh, gw, sample_step, fsx, fsy, mul);

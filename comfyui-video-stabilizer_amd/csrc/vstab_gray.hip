@@ -81,7 +81,11 @@ __global__ __launch_bounds__(1024) void gray_area_int_kernel(const float* __rest
                     sum += gray_u8(cr, cg, cb, fused);
                     if (RANGE) {
                         vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fmaxf(cr, cg), cb));
-                        // per component: a sum probe would also fire on +inf next to -inf, where numpy's max is +inf
+                        // per component: a sum probe would also fire on +inf next to -inf, where numpy's max is +inf.
+                        // (Round 5 tried the NaN-propagating v_maximum3_f32 and v_max3_f32 + a wavefront NaN mask through
+                        // inline asm -- 8 instead of ~70 VALU instructions per four pixels: both SLOWER, 1.27 vs 1.13 ms per
+                        // 256 x 1080p on one box; the asm statements keep the compiler from overlapping the next loads with
+                        // this arithmetic, which is what the pass lives on.  profiles/r05_dis_small_steps.md)
                         has_nan |= ((cr != cr) | (cg != cg) | (cb != cb)) ? 1 : 0;
                     }
                 }
@@ -117,12 +121,15 @@ __global__ __launch_bounds__(1024) void gray_area_int_kernel(const float* __rest
 }
 
 // per-frame maximum of the per-row maxima (NaN wins, as in numpy): one workgroup per frame
-// host_max / host_done (optional): the same value into coherent host memory, then one system-scope count per frame
+// host_max (optional): the maxima also go to coherent host memory -- by the LAST workgroup to finish (a device-scope count
+// finds it), as one coalesced store of all `gridDim.x` values followed by a release store of `target` into host_flag.  (One
+// store + one system-scope atomic per workgroup, the first form of this, serialised 256 PCIe round trips: 276 us.)
 __global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict__ row_max, float* __restrict__ frame_max, int rows,
-                                                        float* host_max, unsigned* host_done)
+                                                        float* host_max, unsigned* host_flag, unsigned* dev_count, unsigned target)
 {
     __shared__ float s_max[4];
     __shared__ int s_nan[4];
+    __shared__ int s_last;
     const float* R = row_max + (size_t)blockIdx.x * rows;
     float vmax = -INFINITY;
     int has_nan = 0;
@@ -140,12 +147,22 @@ __global__ __launch_bounds__(256) void frame_max_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = __builtin_fmaxf(__builtin_fmaxf(s_max[0], s_max[1]), __builtin_fmaxf(s_max[2], s_max[3]));
-        const float v = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
-        frame_max[blockIdx.x] = v;
+        frame_max[blockIdx.x] = (s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3]) ? NAN : m;
+        s_last = 0;
         if (host_max != nullptr) {
-            __hip_atomic_store(host_max + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_fetch_add(host_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the value first, then the count
+            // release the value, count this workgroup; the one that completes the pass's count mirrors all of them
+            const unsigned prev = __hip_atomic_fetch_add(dev_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (prev + 1u == target) ? 1 : 0;
         }
+    }
+    if (host_max == nullptr) return;
+    __syncthreads();
+    if (s_last) {
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+            host_max[i] = __hip_atomic_load(frame_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_flag, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -388,10 +405,14 @@ static int gray_run(vstab_ctx* ctx, const float* frames, int n, int src_h, int s
             VSTAB_HIP(hipHostGetDevicePointer(&dp, hp, 0));
             ctx->h_peaks = static_cast<float*>(hp); ctx->d_peaks_mirror = static_cast<float*>(dp); ctx->h_peaks_cap = cap;
         }
+        if (!ctx->d_peaks_count) {   // the device-side count of finished frames (never reset: passes are told their target)
+            VSTAB_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_peaks_count), 256));
+            VSTAB_HIP(hipMemsetAsync(ctx->d_peaks_count, 0, 256, st));
+        }
         ctx->peaks_target += (unsigned)n;
         ctx->peaks_frames = n;
         hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, range_rows, ctx->d_peaks_mirror,
-                           reinterpret_cast<unsigned*>(ctx->d_status) + VSTAB_PEAKS_DONE_WORD);
+                           reinterpret_cast<unsigned*>(ctx->d_status) + VSTAB_PEAKS_DONE_WORD, ctx->d_peaks_count, ctx->peaks_target);
         VSTAB_HIP(hipGetLastError());
     }
     return 0;
@@ -423,7 +444,7 @@ extern "C" int vstab_gray_downscale_range(vstab_ctx* ctx, const float* frames, i
 }
 
 // The maxima of the latest vstab_gray_downscale_range call, on the host: waits for that call's frame_max_kernel only (a
-// count in coherent host memory the kernel bumps once per frame), not for anything queued behind it.
+// word in coherent host memory that the kernel's last workgroup sets to the pass's target), not for anything queued behind it.
 extern "C" int vstab_last_frame_peaks(vstab_ctx* ctx, int n, float* out)
 {
     VSTAB_REQUIRE(ctx != nullptr && out != nullptr, "vstab_last_frame_peaks: NULL argument");
@@ -465,7 +486,7 @@ extern "C" int vstab_frame_range(vstab_ctx* ctx, const float* frames, int n, int
     KernelTimer timer(ctx, "range");
     if (vec) hipLaunchKernelGGL(row_max_kernel<true>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
     else hipLaunchKernelGGL(row_max_kernel<false>, dim3((unsigned)(n * pieces)), dim3(256), 0, st, frames, row_max, (int)piece);
-    hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces, (float*)nullptr, (unsigned*)nullptr);
+    hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)n), dim3(256), 0, st, row_max, frame_max, (int)pieces, (float*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, 0u);
     VSTAB_HIP(hipGetLastError());
     return 0;
 }

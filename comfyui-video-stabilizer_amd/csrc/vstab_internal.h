@@ -66,12 +66,13 @@ struct vstab_ctx {
     int* d_status = nullptr;
     // F0's per-frame maxima as the gray pass reports them, mirrored into coherent host memory by the kernel that forms them
     // (frame_max_kernel) -- no copy and no event on the stream (those cost the stream ~25 us between the gray pass and the
-    // pyramid, profiles/r05_dis_small_steps.md).  h_status[VSTAB_PEAKS_DONE_WORD] counts the frames written since the context
-    // was created; peaks_target is the count at which the latest range pass is complete (vstab_last_frame_peaks polls it).
+    // pyramid, profiles/r05_dis_small_steps.md).  peaks_target counts the frames of all range passes since the context was created; the pass
+    // that completes it writes that number into h_status[VSTAB_PEAKS_DONE_WORD] behind the values (vstab_last_frame_peaks polls it).
     float* h_peaks = nullptr;       // host pointer
     float* d_peaks_mirror = nullptr;   // the same memory as the device sees it
     int h_peaks_cap = 0, peaks_frames = 0;
     unsigned peaks_target = 0;
+    unsigned* d_peaks_count = nullptr;   // device memory: frames finished since the context was created
     // bulk host <-> device transfers (vstab_xfer.hip): pinned ring, its events, a copy stream
     ScratchBuf h_xfer;
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -87,6 +88,9 @@ struct vstab_ctx {
     // (19 + 27 us of idle GPU per C2 step, profiles/r05_dis_small_steps.md).  fit_copy_bytes > 0: the fit records'
     // download has not been issued yet (vstab_flow_plan_device issues it on the side stream, vstab_sample_fit_batch_end on
     // the call's stream if no plan call came in between).
+    unsigned* plan_zero_ptr = nullptr;     // registered for the next plan kernel to zero (vstab_flow_plan_zero_counts)
+    int plan_zero_n = 0;
+    unsigned* plan_zeroed_ptr = nullptr;   // what the last plan kernel zeroed: the planned warp skips its own fill for it
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr;
     size_t fit_copy_bytes = 0;

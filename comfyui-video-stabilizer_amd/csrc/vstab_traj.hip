@@ -46,6 +46,8 @@ struct PlanArgs {
     double* target;                // [frames][p]
     double* region;                // [4]: x0, y0, x1, y1 of the common region (tests)
     int perturb;                   // tests (VSTAB_DEBUG_PLAN_PERTURB=frame): that frame's matrix is made wrong by one ulp
+    unsigned* zero;                // the planned warp's padded-pixel counts: zeroed here (vstab_flow_plan_zero_counts), or nullptr
+    int zero_n;
 };
 
 // the records of pair i (three, indexed by mode)
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
 {
     extern __shared__ double s_path[];
     const int p = a.mode == VSTAB_MODE_SIMILARITY ? 4 : 2;
+    for (int i = threadIdx.x; i < a.zero_n; i += PLAN_T) a.zero[i] = 0u;   // (a fill kernel of its own cost the stream ~17 us before the warp)
     const int frames = a.pairs + 1, total = frames * p;
     double* s_red = s_path + total;                                  // [4][PLAN_T / 64]
     signed char* s_mode = reinterpret_cast<signed char*>(s_red + 4 * (PLAN_T / 64));   // [pairs]
@@ -319,6 +322,11 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
                                       const double* up, const double* down, double smooth, double fps, double strength,
                                       int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows)
 {
+    // a registered count array belongs to THIS call only, whether it succeeds or not (a refused call must not leave the
+    // pointer behind for a later kernel to write through)
+    unsigned* zero_ptr = ctx ? ctx->plan_zero_ptr : nullptr;
+    const int zero_n = ctx ? ctx->plan_zero_n : 0;
+    if (ctx) { ctx->plan_zero_ptr = nullptr; ctx->plan_zero_n = 0; ctx->plan_zeroed_ptr = nullptr; }
     VSTAB_REQUIRE(ctx != nullptr && d_records != nullptr, "vstab_flow_plan_device: NULL argument");
     VSTAB_REQUIRE(pairs >= 1, "vstab_flow_plan_device: needs at least one transition");
     VSTAB_REQUIRE(requested_mode == VSTAB_MODE_TRANSLATION || requested_mode == VSTAB_MODE_SIMILARITY,
@@ -366,6 +374,8 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     a.target = reinterpret_cast<double*>(base + L.target);
     a.region = reinterpret_cast<double*>(base + L.region);
     a.perturb = -1;
+    a.zero = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
+    ctx->plan_zeroed_ptr = zero_ptr;
 #ifdef VSTAB_TEST_HOOKS   // fault injector of the test build (lib/libvstab_hooks.so); the shipped library reads no such variable
     if (const char* e = getenv("VSTAB_DEBUG_PLAN_PERTURB")) a.perturb = atoi(e);
 #endif
@@ -390,6 +400,16 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     VSTAB_HIP(hipMemcpyAsync(ctx->h_plan.ptr, base, L.xf, hipMemcpyDeviceToHost, ctx->side_stream));
     VSTAB_HIP(hipEventRecord(ctx->ev_plan_done, ctx->side_stream));
     ctx->plan_frames = frames; ctx->plan_params = p;
+    return 0;
+}
+
+// Registers the planned warp's padded-pixel count array with the NEXT vstab_flow_plan_device call: its kernel zeroes the
+// array, and vstab_warp_batch_planned, handed the same pointer, skips its own fill (one launch less between plan and warp).
+extern "C" int vstab_flow_plan_zero_counts(vstab_ctx* ctx, uint32_t* pad_count, int n)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_flow_plan_zero_counts: ctx is NULL");
+    VSTAB_REQUIRE(pad_count != nullptr && n > 0, "vstab_flow_plan_zero_counts: needs a count array of at least one frame");
+    ctx->plan_zero_ptr = pad_count; ctx->plan_zero_n = n;
     return 0;
 }
 

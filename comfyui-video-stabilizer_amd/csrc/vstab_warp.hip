@@ -959,7 +959,8 @@ extern "C" int vstab_warp_batch_planned(vstab_ctx* ctx, const float* src, int fi
     a.xf = xf;
     a.samples = 1; a.nxf_per_frame = 1;
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
-    if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+    if (pad_count && pad_count != ctx->plan_zeroed_ptr) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+    ctx->plan_zeroed_ptr = nullptr;   // (the plan kernel zeroed a registered array once: a second warp into it fills it itself)
     KernelTimer timer(ctx, "warp");
     return launch_warp(a, interp, subpix, mask != nullptr, ctx->stream);
 }

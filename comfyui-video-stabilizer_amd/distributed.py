@@ -402,7 +402,7 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
             # (a peer that failed sent zero records: plan_kernel treats such pairs as "no fit" -- identity -- so the launches
             # below are harmless; this rank learns of the failure from the status rows a few lines down and raises)
             ctx.flow_plan_device(flat.data_ptr(), total_frames - 1, transform_mode, size, working_size, smooth, fps_effective, strength,
-                                 bool(camera_lock), seg_pairs=per_rank, seg_rows=rows + 1)
+                                 bool(camera_lock), seg_pairs=per_rank, seg_rows=rows + 1, warp_frames=n_local)
             if n_local > 0:
                 dst, mask, counts = ctx.warp_batch_planned(own, start, size, border=hm.border_value(padding_rgb), want_mask=True,
                                                            want_count=True)

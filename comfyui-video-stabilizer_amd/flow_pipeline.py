@@ -493,7 +493,7 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
     _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True)
     pairs = ctx.sample_fit_batch_begin(grid, SAMPLE_STEP, transform_mode)
     ctx.flow_plan_device(ctx.fit_records_device(), pairs, transform_mode, size, working_size, smooth, fps_effective, strength,
-                         bool(camera_lock))
+                         bool(camera_lock), warp_frames=total_frames)
     dst, mask, counts = ctx.warp_batch_planned(device_frames, 0, size, border=hm.border_value(padding_rgb), want_mask=True,
                                                want_count=True)
     fit_records = ctx.sample_fit_batch_end(pairs)          # waits for the fits only; the plan kernel and the warp run on

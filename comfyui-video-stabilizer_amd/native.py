@@ -94,6 +94,7 @@ def fit_table_to_dicts(table: np.ndarray):
 
 _SIGNATURES = {
     "vstab_abi_version": (C.c_int, []),
+    "vstab_flow_plan_zero_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_last_frame_peaks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_test_hooks": (C.c_int, []),
     "vstab_last_error": (C.c_char_p, []),
@@ -575,9 +576,16 @@ class Context:
         _check(self.lib.vstab_fit_records_copy(self.handle, _dev_ptr(dst), int(pairs)), "vstab_fit_records_copy")
 
     def flow_plan_device(self, records_ptr, pairs, requested_mode, source_size, working_size, smooth, fps, strength, camera_lock,
-                         seg_pairs=None, seg_rows=0):
+                         seg_pairs=None, seg_rows=0, warp_frames=0):
         """Queue plan_kernel behind the fits: records (device address) -> the warp's transform table, on the device.
-        seg_pairs / seg_rows: the records are an all-gather's receive buffer (seg_rows pairs per rank, seg_pairs[r] valid)."""
+        seg_pairs / seg_rows: the records are an all-gather's receive buffer (seg_rows pairs per rank, seg_pairs[r] valid).
+        warp_frames: frames the following warp_batch_planned(want_count=True) will warp -- its count array is allocated here
+        and zeroed by the plan kernel, so that no fill launch sits between plan and warp."""
+        self._planned_counts = None
+        if warp_frames:
+            self._planned_counts = self.torch.empty((int(warp_frames),), dtype=self.torch.int32, device=self.device)
+            _check(self.lib.vstab_flow_plan_zero_counts(self.handle, _dev_ptr(self._planned_counts), int(warp_frames)),
+                   "vstab_flow_plan_zero_counts")
         up = down = None
         if working_size is not None:
             sx, sy = working_size[0] / float(source_size[0]), working_size[1] / float(source_size[1])
@@ -613,7 +621,12 @@ class Context:
         b = np.ascontiguousarray(border, dtype=np.float32).reshape(3)
         dst = torch.empty((n, out_h, out_w, 3), dtype=torch.float32, device=self.device)
         mask = torch.empty((n, out_h, out_w), dtype=torch.float32, device=self.device) if want_mask else None
-        counts = torch.empty((n,), dtype=torch.int32, device=self.device) if (want_count and want_mask) else None
+        counts = None
+        if want_count and want_mask:
+            counts = getattr(self, "_planned_counts", None)      # zeroed by the plan kernel, if the plan call was told of this warp
+            self._planned_counts = None
+            if counts is None or counts.shape[0] != n:
+                counts = torch.empty((n,), dtype=torch.int32, device=self.device)
         self.use_torch_stream()
         _check(self.lib.vstab_warp_batch_planned(
             self.handle, _dev_ptr(src), int(first), n, sh, sw, out_h, out_w, INTERP["bilinear"], b.ctypes.data,

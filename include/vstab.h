@@ -306,6 +306,9 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
  * download only).  The device forms atan2 / log / exp / cos / sin with its own fp64 library, the reference with the host's
  * libm: the caller computes the plan on the host as well (vstab_transitions_to_params ... vstab_bounding_boxes), compares
  * the final matrices bit for bit and warps a frame again where they differ -- see flow_pipeline.py. */
+/* Optional, before vstab_flow_plan_device: the planned warp's padded-pixel count array (dev [n] u32); the plan kernel zeroes
+ * it, and vstab_warp_batch_planned with the same pointer skips its own fill -- one launch less between plan and warp. */
+int vstab_flow_plan_zero_counts(vstab_ctx* ctx, uint32_t* pad_count, int n);
 int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
                            const double* up, const double* down, double smooth, double fps, double strength,
                            int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows);

@@ -5,8 +5,12 @@ rounded f32 divide/sqrt, OpenCV's 4-lane row-accumulator association for the pat
 tests/test_dis_sum_order_cpu.py), so every data-dependent branch of the inverse search takes the same path.  The independent check (known synthetic camera
 motion) bounds the end result without reference to OpenCV's intermediate values."""
 
+from pathlib import Path
+
 import numpy as np
 import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +181,37 @@ def test_dis_split_and_fused_launch_forms_match_oracle(ctx, oracle, monkeypatch,
     ref = oracle.dis_flow_clip(gray)
     assert np.array_equal(flow.cpu().numpy(), ref)
     assert np.array_equal(grid.cpu().numpy(), ref[:, ::8, ::8, :])
+
+
+def test_pyramid_tail_launch_equals_the_per_level_launches(ctx, oracle, tmp_path):
+    """`pyramid_tail_kernel` (the pyramid's coarse levels + the coarsest level's padded copy / gradients / structure tensor in
+    ONE launch) against the per-level launches of rounds 1-4, which VSTAB_DIS_PYRAMID_TAIL=0 brings back (read once per
+    process: a child).  Same flow bits, on a clip whose pyramid has general-ratio steps (135 -> 67 -> 33 -> 16 rows) and on
+    a small one with fewer levels; both equal the oracle."""
+    import subprocess
+    import sys
+
+    import torch
+
+    for n, h, w, seed in ((3, 540, 960, 11), (3, 136, 240, 12)):
+        gray, _ = moving_clip(n, h, w, seed=seed)
+        np.save(tmp_path / "gray.npy", gray)
+        code = f"""
+import sys; sys.path.insert(0, {str(ROOT)!r})
+import numpy as np, torch
+import __graft_entry__ as graft
+graft.load_package()
+from vstab_amd import native
+ctx = native.Context(0)
+flow, grid = ctx.dis_flow_batch(torch.from_numpy(np.load({str(tmp_path / 'gray.npy')!r})), sample_step=8, want_full=True, want_grid=True)
+np.save({str(tmp_path / 'flow_off.npy')!r}, flow.cpu().numpy()); np.save({str(tmp_path / 'grid_off.npy')!r}, grid.cpu().numpy())
+"""
+        import os
+
+        env = dict(os.environ, VSTAB_DIS_PYRAMID_TAIL="0")
+        proc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        flow, grid = ctx.dis_flow_batch(torch.from_numpy(gray), sample_step=8, want_full=True, want_grid=True)
+        assert np.array_equal(flow.cpu().numpy(), np.load(tmp_path / "flow_off.npy"))
+        assert np.array_equal(grid.cpu().numpy(), np.load(tmp_path / "grid_off.npy"))
+        assert np.array_equal(flow.cpu().numpy(), oracle.dis_flow_clip(gray))

@@ -125,3 +125,31 @@ def test_range_sniff_with_both_infinities(ctx, oracle):
     assert np.array_equal(peaks.cpu().numpy(), want)
     assert np.array_equal(ctx.frame_range(frames).cpu().numpy(), want)
     assert np.array_equal(oracle.frame_max(frames), want)
+
+
+def test_frame_maxima_reach_the_host_without_a_copy(ctx):
+    """The kernel that forms the per-frame maxima mirrors them into coherent host memory (its last workgroup: one store of
+    all values, then a flag); `last_frame_peaks` waits for that kernel alone.  The host values are the device tensor's,
+    NaN and infinities included, across passes of different frame counts (the pass's target count is cumulative), and
+    `host_math.apply_value_range` takes them from there (`_vstab_fetch`) instead of a transfer of its own."""
+    import torch
+    from vstab_amd import host_math as hm
+
+    for n, seed in ((3, 1), (1, 2), (40, 3), (3, 4)):
+        frames = synth_frames(n, 90, 160, seed=seed)
+        frames[0, 3, 4, 1] = 7.5
+        if n > 2:
+            frames[1, 5, 6, 2] = np.nan
+            frames[2, 1, 1, 0] = -np.inf
+        gray, peaks = ctx.gray_downscale(frames, None, want_range=True)
+        host = ctx.last_frame_peaks(n)
+        assert host.dtype == np.float32 and np.array_equal(host, peaks.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(host, frames.reshape(n, -1).max(axis=1), equal_nan=True)
+        assert hasattr(peaks, "_vstab_fetch") and hm.prefetch_peaks(peaks) is peaks
+        dev = torch.from_numpy(frames).cuda()
+        rescaled, vrange = hm.apply_value_range(dev, peaks, ctx)
+        want = frames.copy()
+        want[0] /= np.float32(255.0)
+        assert vrange == "0_255" and np.array_equal(rescaled.cpu().numpy(), want, equal_nan=True)
+    with pytest.raises(Exception, match="no range pass over 5 frames"):
+        ctx.last_frame_peaks(5)
