@@ -156,6 +156,7 @@ int vstab_destroy(vstab_ctx* ctx)
     ctx->h_plan.release();
     if (ctx->h_peaks) (void)hipHostFree(ctx->h_peaks);
     if (ctx->d_peaks_count) (void)hipFree(ctx->d_peaks_count);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->ev_fit_done) (void)hipEventDestroy(ctx->ev_fit_done);
     if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }

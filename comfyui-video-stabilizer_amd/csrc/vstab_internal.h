@@ -73,6 +73,14 @@ struct vstab_ctx {
     int h_peaks_cap = 0, peaks_frames = 0;
     unsigned peaks_target = 0;
     unsigned* d_peaks_count = nullptr;   // device memory: frames finished since the context was created
+    // The plain warp's per-frame padded-pixel counts reach the host the same way: a one-workgroup kernel behind the warp
+    // copies them into coherent host memory and sets h_status[VSTAB_COUNTS_DONE_WORD] to the call's generation number, which
+    // vstab_last_pad_counts polls -- the step's last host wait costs the flag's round trip instead of a copy + a stream
+    // synchronisation (~30 us of GPU idle between two steps).
+    unsigned* h_counts = nullptr;
+    unsigned* d_counts_mirror = nullptr;
+    int h_counts_cap = 0, counts_n = 0;
+    unsigned counts_gen = 0;
     // bulk host <-> device transfers (vstab_xfer.hip): pinned ring, its events, a copy stream
     ScratchBuf h_xfer;
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -101,7 +109,7 @@ struct vstab_ctx {
     hipEvent_t ev_pyramid = nullptr;
 };
 
-enum { VSTAB_PEAKS_DONE_WORD = 4 };      // index into h_status / d_status (the status word itself is [0])
+enum { VSTAB_PEAKS_DONE_WORD = 4, VSTAB_COUNTS_DONE_WORD = 5 };      // index into h_status / d_status (the status word itself is [0])
 enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired
 
 // Call after a host synchronisation of ctx->stream: turns a device-side failure report into a non-zero return

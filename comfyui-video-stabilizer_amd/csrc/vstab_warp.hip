@@ -921,6 +921,57 @@ void fill_geometry(WarpArgs& a, int n, int sh, int sw, int dh, int dw, const flo
 
 }  // namespace
 
+// ---- the counts' way to the host (see vstab_internal.h) ----
+namespace {
+__global__ __launch_bounds__(256) void mirror_counts_kernel(const uint32_t* __restrict__ counts, unsigned* host, int n, unsigned* flag, unsigned gen)
+{
+    for (int i = threadIdx.x; i < n; i += 256) host[i] = counts[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int mirror_counts(vstab_ctx* ctx, const uint32_t* pad_count, int n)
+{
+    if (ctx->h_counts_cap < n) {
+        if (ctx->h_counts) { VSTAB_HIP(hipStreamSynchronize(ctx->stream)); VSTAB_HIP(hipHostFree(ctx->h_counts)); ctx->h_counts = nullptr; ctx->h_counts_cap = 0; }
+        const int cap = n > 4096 ? n : 4096;
+        void* hp = nullptr;
+        VSTAB_HIP(hipHostMalloc(&hp, sizeof(unsigned) * (size_t)cap, hipHostMallocMapped | hipHostMallocCoherent));
+        void* dp = nullptr;
+        VSTAB_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        ctx->h_counts = static_cast<unsigned*>(hp); ctx->d_counts_mirror = static_cast<unsigned*>(dp); ctx->h_counts_cap = cap;
+    }
+    ctx->counts_gen += 1;
+    ctx->counts_n = n;
+    hipLaunchKernelGGL(mirror_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, pad_count, ctx->d_counts_mirror, n,
+                       reinterpret_cast<unsigned*>(ctx->d_status) + VSTAB_COUNTS_DONE_WORD, ctx->counts_gen);
+    VSTAB_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+// The padded-pixel counts of the latest vstab_warp_batch / vstab_warp_batch_planned call that asked for them, on the host:
+// waits for that call's kernels only (a word in coherent host memory), nothing is copied by the caller.
+extern "C" int vstab_last_pad_counts(vstab_ctx* ctx, int n, uint32_t* out)
+{
+    VSTAB_REQUIRE(ctx != nullptr && out != nullptr, "vstab_last_pad_counts: NULL argument");
+    VSTAB_REQUIRE(ctx->h_counts != nullptr && n == ctx->counts_n, "vstab_last_pad_counts: no warp with counts over %d frames is pending", n);
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(ctx->h_status) + VSTAB_COUNTS_DONE_WORD;
+    const unsigned gen = ctx->counts_gen;
+    for (long spins = 0; *done != gen; spins++) {
+        if (spins > 200000000L) {   // ~10 s: a warp of a long 4K clip takes tens of milliseconds; then the runtime's own report
+            VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+            VSTAB_REQUIRE(*done == gen, "vstab_last_pad_counts: the warp finished without reporting its counts");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    memcpy(out, ctx->h_counts, sizeof(uint32_t) * (size_t)n);
+    return 0;
+}
+
 extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src_h, int src_w, const float* matrices,
                                 int out_h, int out_w, int interp, const float* border_rgb, int subpix, float* dst,
                                 float* mask, uint32_t* pad_count)
@@ -938,8 +989,11 @@ extern "C" int vstab_warp_batch(vstab_ctx* ctx, const float* src, int n, int src
     a.samples = 1; a.nxf_per_frame = 1;
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     if (pad_count) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
-    KernelTimer timer(ctx, "warp");
-    return launch_warp(a, interp, subpix, mask != nullptr, ctx->stream);
+    {
+        KernelTimer timer(ctx, "warp");
+        if (int rc = launch_warp(a, interp, subpix, mask != nullptr, ctx->stream)) return rc;
+    }
+    return pad_count ? mirror_counts(ctx, pad_count, n) : 0;
 }
 
 const WarpXform* vstab_plan_xforms(vstab_ctx* ctx, int first, int n);   // vstab_traj.hip
@@ -961,8 +1015,11 @@ extern "C" int vstab_warp_batch_planned(vstab_ctx* ctx, const float* src, int fi
     fill_geometry(a, n, src_h, src_w, out_h, out_w, border_rgb, dst, mask);
     if (pad_count && pad_count != ctx->plan_zeroed_ptr) VSTAB_HIP(hipMemsetAsync(pad_count, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
     ctx->plan_zeroed_ptr = nullptr;   // (the plan kernel zeroed a registered array once: a second warp into it fills it itself)
-    KernelTimer timer(ctx, "warp");
-    return launch_warp(a, interp, subpix, mask != nullptr, ctx->stream);
+    {
+        KernelTimer timer(ctx, "warp");
+        if (int rc = launch_warp(a, interp, subpix, mask != nullptr, ctx->stream)) return rc;
+    }
+    return pad_count ? mirror_counts(ctx, pad_count, n) : 0;
 }
 
 // motion_apply.py:125-134 (_blurred_matrix_samples) + the f32 cast of motion_apply.py:172, for frames

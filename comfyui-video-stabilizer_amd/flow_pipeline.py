@@ -464,6 +464,13 @@ def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, 
             and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES and 1 <= segments <= _DEVICE_PLAN_MAX_SEGMENTS)
 
 
+def _counts_to_host(counts, mirrored: bool = True) -> np.ndarray:
+    """The warp's per-frame padded-pixel counts on the host: from the mirror the library keeps behind the warp kernel (no copy,
+    no stream synchronisation of ours) where the tensor carries its fetch handle, else by a transfer."""
+    fetch = getattr(counts, "_vstab_fetch", None) if mirrored else None
+    return fetch() if fetch is not None else counts.cpu().numpy()
+
+
 def _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb) -> int:
     """Frames whose device-plan matrix is not the host plan's, bit for bit, are warped again with the host's."""
     host = np.ascontiguousarray(plan.final_matrices, np.float32)
@@ -506,8 +513,10 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
     meta = prepare_meta(plan)                               # host JSON work overlaps the warp kernel
     final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
     verdict = {"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb)}
-    meta = complete_meta(meta, plan, counts.cpu().numpy())
-    _replay_progress(pbar, progress_done, total_frames, progress_total)
+    _replay_progress(pbar, progress_done, total_frames, progress_total)   # (host work that needs no pixel: before the last wait)
+    # the warp's counts: mirrored to the host behind the kernel (native.last_pad_counts) -- unless frames were warped again,
+    # whose counts went into the device tensor only
+    meta = complete_meta(meta, plan, _counts_to_host(counts, mirrored=verdict["mismatched_frames"] == 0))
     check_interrupt()
     if keep_on_device:
         return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta, verdict)
@@ -626,8 +635,8 @@ def _stabilize_frames(
         device_frames, plan.final_matrices, plan.output_size, interp="bilinear",
         border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
     meta = prepare_meta(plan)  # host JSON work overlaps the warp kernel
-    meta = complete_meta(meta, plan, counts.cpu().numpy())
     progress_done = _replay_progress(pbar, progress_done, total_frames, progress_total)
+    meta = complete_meta(meta, plan, _counts_to_host(counts))
     check_interrupt()
     verdict = {"used": False, "mismatched_frames": 0}
     if keep_on_device:

@@ -94,6 +94,7 @@ def fit_table_to_dicts(table: np.ndarray):
 
 _SIGNATURES = {
     "vstab_abi_version": (C.c_int, []),
+    "vstab_last_pad_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_flow_plan_zero_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_last_frame_peaks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_test_hooks": (C.c_int, []),
@@ -416,6 +417,8 @@ class Context:
             ),
             "vstab_warp_batch",
         )
+        if counts is not None and out is None:
+            counts._vstab_fetch = lambda n=n: self.last_pad_counts(n)   # valid until the next warp with counts of this context
         return dst, mask, counts
 
     def warp_blur_batch(self, frames, matrices64, out_size, blur, samples, interp="bilinear",
@@ -472,6 +475,12 @@ class Context:
         _check(self.lib.vstab_gray_downscale(self.handle, _dev_ptr(src), n, sh, sw, wh, ww, _dev_ptr(gray)),
                "vstab_gray_downscale")
         return gray
+
+    def last_pad_counts(self, n: int) -> np.ndarray:
+        """Host copy of the padded-pixel counts of the latest warp_batch / warp_batch_planned(want_count=True) over n frames."""
+        out = np.empty((int(n),), np.uint32)
+        _check(self.lib.vstab_last_pad_counts(self.handle, int(n), out.ctypes.data), "vstab_last_pad_counts")
+        return out.astype(np.int64)
 
     def last_frame_peaks(self, n: int) -> np.ndarray:
         """Host copy of the per-frame maxima of the latest gray_downscale(..., want_range=True) over n frames."""
@@ -632,6 +641,8 @@ class Context:
             self.handle, _dev_ptr(src), int(first), n, sh, sw, out_h, out_w, INTERP["bilinear"], b.ctypes.data,
             SUBPIX[subpix or DEFAULT_SUBPIX], _dev_ptr(dst), _dev_ptr(mask) if mask is not None else None,
             _dev_ptr(counts) if counts is not None else None), "vstab_warp_batch_planned")
+        if counts is not None:
+            counts._vstab_fetch = lambda n=n: self.last_pad_counts(n)   # valid until the next warp with counts of this context
         return dst, mask, counts
 
     # ------------------------------------------------------------------ Classic estimator (sparse features + LK)

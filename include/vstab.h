@@ -324,6 +324,11 @@ int vstab_flow_plan_result(vstab_ctx* ctx, int frames, float* final32, double* p
 int vstab_warp_batch_planned(vstab_ctx* ctx, const float* src, int first, int n, int src_h, int src_w, int out_h,
                              int out_w, int interp, const float* border_rgb, int subpix, float* dst, float* mask,
                              uint32_t* pad_count);
+/* The per-frame padded-pixel counts of the latest vstab_warp_batch / vstab_warp_batch_planned call that was given a
+ * pad_count array, on the host (n = that call's frame count): a one-workgroup kernel behind the warp mirrors them into
+ * coherent host memory, this call waits for it -- the host side of `mask.mean()` per frame (video_stabilizer_flow.py:583-588)
+ * without a copy or a stream synchronisation of the caller's. */
+int vstab_last_pad_counts(vstab_ctx* ctx, int n, uint32_t* out);
 
 /* ---- F6 / F9 host helper: element-wise libm over fp64 arrays (host pointers, no GPU involved) ----
  * nodes/stabilizer_utils.py:300-358 (_matrix_to_params / _params_to_matrix) call math.sqrt/atan2/log and

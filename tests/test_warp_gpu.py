@@ -330,3 +330,20 @@ def test_blur_exact_subpixel_mode_staged_path_matches_oracle(ctx, oracle, kind, 
     finally:
         del os.environ["VSTAB_BLUR_FAST"]
     assert bool((gen == dst).all()) and bool((gen_mask == mask).all())
+
+
+def test_pad_counts_reach_the_host_behind_the_warp(ctx):
+    """The plain warp's per-frame padded-pixel counts are mirrored into coherent host memory by a one-workgroup kernel behind
+    the warp; `last_pad_counts` waits for that word alone.  Same numbers as the device tensor, for calls of different
+    frame counts in a row, and the handle refuses a stale frame count."""
+    import torch
+
+    for n, seed in ((5, 1), (1, 2), (33, 3)):
+        frames = torch.from_numpy(synth_frames(n, 72, 128, seed=seed)).cuda()
+        mats = test_matrices(n, 128, 72, "similarity", seed=seed).astype(np.float32)
+        _, mask, counts = ctx.warp_batch(frames, mats, (128, 72), border=(0.5, 0.5, 0.5), want_mask=True, want_count=True)
+        host = counts._vstab_fetch()
+        assert np.array_equal(host, counts.cpu().numpy().astype(np.int64))
+        assert np.array_equal(host, (mask.cpu().numpy() > 0).reshape(n, -1).sum(axis=1))
+    with pytest.raises(Exception, match="no warp with counts over 7 frames"):
+        ctx.last_pad_counts(7)
