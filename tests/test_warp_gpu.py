@@ -340,7 +340,7 @@ def test_pad_counts_reach_the_host_behind_the_warp(ctx):
 
     for n, seed in ((5, 1), (1, 2), (33, 3)):
         frames = torch.from_numpy(synth_frames(n, 72, 128, seed=seed)).cuda()
-        mats = test_matrices(n, 128, 72, "similarity", seed=seed).astype(np.float32)
+        mats = make_matrices(n, 128, 72, "similarity", seed=seed).astype(np.float32)
         _, mask, counts = ctx.warp_batch(frames, mats, (128, 72), border=(0.5, 0.5, 0.5), want_mask=True, want_count=True)
         host = counts._vstab_fetch()
         assert np.array_equal(host, counts.cpu().numpy().astype(np.int64))

@@ -69,7 +69,7 @@ def step_device_plan(tm):
     host_t = torch.empty(flat.shape, dtype=torch.uint8, pin_memory=True)
     host_t.copy_(flat, non_blocking=True)
     gathered = torch.cuda.Event(); gathered.record()
-    ctx.flow_plan_device(flat.data_ptr(), total - 1, "similarity", size, work, 0.5, 16.0, 0.7, False, seg_pairs=per_rank, seg_rows=rows)
+    ctx.flow_plan_device(flat.data_ptr(), total - 1, "similarity", size, work, 0.5, 16.0, 0.7, False, seg_pairs=per_rank, seg_rows=rows, warp_frames=n)
     dst, mask, counts = ctx.warp_batch_planned(frames, 0, size, border=hm.border_value((127, 127, 127)), want_mask=True, want_count=True)
     t1 = time.perf_counter()
     ctx.sample_fit_batch_end(pairs)
@@ -84,7 +84,7 @@ def step_device_plan(tm):
     t3 = time.perf_counter()
     meta = fp.prepare_meta(plan)
     t4 = time.perf_counter()
-    c = counts.cpu().numpy()
+    c = fp._counts_to_host(counts, mirrored=(bad == 0))
     t5 = time.perf_counter()
     meta = fp.complete_meta(meta, plan, np.tile(c, W))
     t6 = time.perf_counter()
