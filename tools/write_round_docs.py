@@ -7,7 +7,7 @@ import csv, json, re, shutil, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G, P = ROOT / "gpurun_out", ROOT / "profiles"
 
 
@@ -28,6 +28,9 @@ ks = "| kernel | calls | avg us | us per 256-frame clip |\n|---|---|---|---|\n" 
 per_clip = {n.split("<")[0]: c / steps * a for n, c, a in rows}
 
 j = line(f"{TAG}_bench_c2.log")
+TREES = (G / f"{TAG}_trees_ab.txt").read_text().strip() if (G / f"{TAG}_trees_ab.txt").exists() else "(not collected)"
+tj = json.loads((P / "warp_traffic.json").read_text())
+TRAFFIC = f"{tj['hbm_bytes_per_launch'] / 1e9:.4f} GB = {tj['hbm_bytes_per_launch'] / tj['algorithmic_bytes_per_launch']:.4f} of algorithmic"
 acc, par, ma = j["accuracy"]["hip"], j["parity_at_size"], j["motion_apply"]
 c3, c5m = ma["c3_1080p_bicubic_blur0.5_S17"], ma["c5_4k_expand_bilinear_blur0.5_S33"]
 st, cb, rf = j["config"]["stage_ms"], j["cpu_baseline"], j["roofline"]
@@ -37,13 +40,20 @@ Command (one MI355X box, `tools/final_profiles.sh {TAG}`): `python bench.py --st
 `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-extras --no-checks
 --cpu-frames 0` -> `profiles/{TAG}_bench_c2_kernel_stats.csv` ({steps} steps incl. warm-up).
 
-**{j["value"]:.0f} frames/s, {j["ms_per_step"]} ms per 256-frame 1080p clip** (round 3's driver line: 31 743 / 8.065 ms; the boxes of the pool
-differ by ~5-8 % in HBM rate: the same build gave 7.43-7.87 ms over this round's boxes).  HIP-event stage times of the timed
-steps: gray {st["gray"]} / DIS {st["dis"]} / fit {st["fit"]} / warp {st["warp"]} ms (sum {sum(st.values()):.2f}; the rest: inter-kernel gaps of the DIS chain
-and the final sync -- the fit -> plan -> warp stretch no longer waits for the host, `profiles/r04_device_plan.md`).  Roofline of the
-warp kernel: 14.864 GB algorithmic / {rf["launch_ms"]} ms = {rf["achieved"]} GB/s = **{rf["frac"]} of 8 TB/s** on this box; PMC traffic per launch
-`profiles/warp_traffic.json` (FETCH_SIZE x 2 + WRITE_SIZE, re-collected on this round's final warp sources, hash-tied): 14.8617 GB =
-0.9999 of algorithmic.
+**{j["value"]:.0f} frames/s, {j["ms_per_step"]} ms per 256-frame 1080p clip** (round 4's driver line: 34 499 / 7.421 ms; the boxes of the pool
+differ by ~5-8 % in HBM rate, so rounds are compared on ONE box: `{TAG}_trees_ab.txt` below).  Stage times: warp {st["warp"]} ms from HIP events
+inside the timed steps; gray {st["gray"]} / DIS {st["dis"]} / fit {st["fit"]} ms from three extra passes after them (an event pair costs the stream
+~10 us, so the timed steps keep the warp's only); DIS by stage (one more pass, `vstab_set_timing(ctx, 2)`): {j["config"]["dis_ms"]}.
+Device plan in the timed steps: {j["config"]["device_plan"]}.  Roofline of the warp kernel: 14.864 GB algorithmic / {rf["launch_ms"]} ms =
+{rf["achieved"]} GB/s = **{rf["frac"]} of 8 TB/s** on this box; PMC traffic per launch `profiles/warp_traffic.json` (FETCH_SIZE x 2 + WRITE_SIZE,
+re-collected on this round's final warp sources, hash-tied): {TRAFFIC}.
+
+Round-4 tree and this tree on the same box, interleaved (`bench.py --steps 20 --warmup 5 --no-extras --no-checks --cpu-frames 0`; value, ms per
+step, stage ms):
+
+```
+{TREES}
+```
 
 Self-verification on the same line (`accuracy`, `parity_at_size`, `batch_invariance`; outside the timed loop):
 
@@ -59,7 +69,8 @@ Self-verification on the same line (`accuracy`, `parity_at_size`, `batch_invaria
 
 `cpu_baseline`: kind "{cb["kind"]}", cv2 "{cb["cv2"]}" (no OpenCV on the box: the run-time tier decision of `bench.cv2_leg` printed it),
 {cb["value"]:.0f} frames/s on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["os_cpu_count"]} logical CPUs; stage seconds {cb["stage_s"]}) -- ~{j["value"] / cb["value"]:.0f}x, a
-baseline, not a target.  `host_roundtrip` {j["host_roundtrip"]["ms"]} ms ({j["host_roundtrip"]["frames_per_s"]} frames/s, CPU tensor in -> CPU tensors out).
+baseline, not a target; on ALL {cb.get("all_cores", {}).get("cores")} CPUs this process may use: {cb.get("all_cores", {}).get("value", 0):.0f} frames/s (stage seconds
+{cb.get("all_cores", {}).get("stage_s")}) -- slower than on 16: the port's OpenMP loops are memory-bound and its fit stage is serial.  `host_roundtrip` {j["host_roundtrip"]["ms"]} ms ({j["host_roundtrip"]["frames_per_s"]} frames/s, CPU tensor in -> CPU tensors out).
 `motion_apply` (shake-generator motion, affine): C3 kind {c3["ms_per_pass"]} ms per 256x1080p ({c3["frames_per_s"]} frames/s), C5 share {c5m["ms_per_pass"]} ms
 per 64x4K ({c5m["frames_per_s"]} frames/s); frame 1 of each against the oracle: {c3.get("oracle_spot_check")} / {c5m.get("oracle_spot_check")}.
 
@@ -67,7 +78,7 @@ per 64x4K ({c5m["frames_per_s"]} frames/s); frame 1 of each against the oracle: 
 
 {ks}
 DIS = `pis4_kernel` {per_clip.get("pis4_kernel", 0) / 1e3:.2f} + `level_kernel` {per_clip.get("level_kernel", 0) / 1e3:.2f} ms + preparation (pyramid, padding, Sobel, tensors; partly on a
-second stream); round 3: 1.42 + 2.07, round 2: 1.46 + 2.31.
+second stream); round 4: 1.39 + 1.81, round 3: 1.42 + 2.07, round 2: 1.46 + 2.31.
 """)
 
 c5p, c5d, c3p = line(f"{TAG}_bench_c5_plain.log"), line(f"{TAG}_bench_c5_dist1.log"), line(f"{TAG}_bench_c3_plain.log")
@@ -83,16 +94,16 @@ Motion Apply (expand, bilinear, 0.5, Ultra = 33 samples).
 | run | frames/s | ms per step | gray | DIS | fit | warp (Flow's own output) | blur warp | host |
 |---|---|---|---|---|---|---|---|---|
 | `--workload c3` | {c3p["value"]} | {c3p["ms_per_step"]} | {s3["gray"]} | {s3["dis"]} | {s3["fit"]} | {s3["warp"]} | {s3["warp_blur"]} | -- |
-| (the same before perspective samples were staged, earlier in the round) | 4114 | 62.22 | 0.989 | 3.197 | 1.529 | 2.602 | 52.56 | -- |
-| (`--workload c5` before the bilinear weights moved to registers) | 2217 | 28.87 | 0.934 | 1.872 | 0.107 | 2.896 | 21.97 | -- |
+| (round 4's `--workload c3`, other box) | 5469 | 46.81 | 0.99 | 3.19 | 1.52 | 2.60 | 37.1 | -- |
+| (round 4's `--workload c5`, other box) | 2318 | 27.61 | 0.93 | 1.87 | 0.11 | 2.90 | 21.0 | -- |
 | `--workload c5` (single process) | {c5p["value"]} | {c5p["ms_per_step"]} | {sp["gray"]} | {sp["dis"]} | {sp["fit"]} | {sp["warp"]} | {sp["warp_blur"]} | -- |
 | `--workload c5 --gpus 1 --force-dist` (sharded code path inside a world-1 RCCL group) | {c5d["value"]} | {c5d["ms_per_step"]} | {sd["gray"]} | {sd["dis"]} | {sd["fit"]} | {sd["warp"]} | {sd["warp_blur"]} | gather_fits {hd["gather_fits"]}, plan {hd["plan"]}, meta {hd["meta"]} ms |
 
-C5's output canvas: {shape[2]}x{shape[1]} (expand).  Both chains are the blur warp: C3's Flow half reports PERSPECTIVE matrices, so its
-blur samples have a perspective row -- round 3's staged path took affine samples only and the whole C3 chain ran the general
-(L1-bound) loop, which the `motion_apply` extra of the C2 line (affine shake-generator motion) never showed; `--workload c3`, new
-this round, did.  Parity at these sizes: `tests/test_configs_gpu.py` (C3: all 255 pairs + blurred frames {{0, 1, 127, 254, 255}};
-C5: all 63 pairs, warped frames {{0, 31, 63}}, blurred frames {{0, 1, 31, 62, 63}}, bit-exact against the oracle).
+C5's output canvas: {shape[2]}x{shape[1]} (expand).  Both chains are the blur warp.  Round 5 on C3: the perspective fit (`fit` column) fell from
+1.52 to ~1.1 ms (`profiles/r05_homography.md`), and tiles whose staged window lies inside the source take the interior loop for perspective
+samples too (blur warp 37.1 -> ~36 ms; the per-pixel fp64 reciprocal of the denominator is the contract and stays).  Parity at these sizes:
+`tests/test_configs_gpu.py` (C3: all 255 pairs + blurred frames {{0, 1, 127, 254, 255}}; C5: all 63 pairs, warped frames {{0, 31, 63}}, blurred
+frames {{0, 1, 31, 62, 63}}, bit-exact against the oracle).
 """)
 
 c4, d1 = line(f"{TAG}_c4_single_gpu.log"), line(f"{TAG}_c4_dist1_128.log")
@@ -113,24 +124,23 @@ reason); this is an ESTIMATE from one box (`tools/final_profiles.sh {TAG}`), not
 
 | measurement | ms per step |
 |---|---|
-| the whole clip on one GPU (`bench.py --gpus 1 --total-frames 1024`) | **{one}** ({c4["value"]:.0f} frames/s; gray {cs["gray"]}, DIS {cs["dis"]}, fit {cs["fit"]}, warp {cs["warp"]}) -- round 3: 29.5-30.3 |
-| one rank's share through the sharded code inside a world-1 RCCL group, device plan (`--gpus 1 --force-dist --total-frames 128`) | {d1["ms_per_step"]} (gray {ds["gray"]}, DIS {ds["dis"]} split form, fit {ds["fit"]}, warp {ds["warp"]}; host: {dh}) -- round 3: 4.9-5.0 |
+| the whole clip on one GPU (`bench.py --gpus 1 --total-frames 1024`) | **{one}** ({c4["value"]:.0f} frames/s; gray {cs["gray"]}, DIS {cs["dis"]}, fit {cs["fit"]}, warp {cs["warp"]}) -- round 4: 28.2, round 3: 29.5-30.3 |
+| one rank's share through the sharded code inside a world-1 RCCL group, device plan (`--gpus 1 --force-dist --total-frames 128`) | {d1["ms_per_step"]} (gray {ds["gray"]}, DIS {ds["dis"]} split form, fit {ds["fit"]}, warp {ds["warp"]}; host: {dh}) -- round 4: 4.61, round 3: 4.9-5.0 |
 | rank 0's step of an N-rank run with the gathered tables of N ranks, no collective (`tools/emulate_world.py`) | see below |
 
 ```
 {em}
 ```
 
-| ranks | frames per rank | rank 0's step, host plan (rounds 1-3 flow), ms | device plan (round 4), ms | + 0.2-0.4 ms RCCL -> speed-up vs {one} ms |
+| ranks | frames per rank | rank 0's step, host plan (rounds 1-3 flow), ms | device plan (rounds 4-5), ms | + 0.2-0.4 ms RCCL -> speed-up vs {one} ms |
 |---|---|---|---|---|
 {table}
-Still **short of the >= 6x target at 8 GPUs** (needs <= {one / 6 - 0.3:.2f} ms per rank incl. RCCL): the one-GPU time of the same clip fell
-with the DIS work of this round as well, so the ratio moved less than the per-rank time did.  A rank's 128-frame step is now
-4.41 ms of GPU span (`gpurun_out/r04_step_timeline128.txt`: gray 0.53, pyramid + per-level preparation 0.23, patch search 1.04,
-refinement 1.07, fit 0.11, plan kernel 0.02, warp 1.33, gaps 0.09) -- the host no longer sits between the fits and the warp; what
-keeps it from 3.5 ms (= 28.5 / 8) is unchanged: the coarse-to-fine chain's latency floor (the three coarse levels cost 0.8 ms for
-any number of pairs, the finest patch search 0.62 ms for 127 pairs vs 0.82 for 255) and the per-level preparation launches.  Weak
-scaling (256 frames per GPU, `--frames 256`) has neither problem.
+Still **short of the >= 6x target at 8 GPUs** (needs <= {one / 6 - 0.3:.2f} ms per rank incl. RCCL); round 4's estimate was 5.34-5.54x (4.89 ms per
+rank against 28.2 ms).  What moved the per-rank step this round is what sat BETWEEN its kernels -- the copies and events on the stream, the
+fill before the warp, the final sampling launch, the counts' way to the host (`profiles/r05_dis_small_steps.md`): per step those cost the same
+at 128 frames as at 256, so they weigh twice as much in a rank's step.  What keeps it from {one / 8:.2f} ms (= {one} / 8) is unchanged: the
+coarse-to-fine chain's per-level cost at 127 pairs (patch search 1.04 ms, refinement 1.07 ms in the split form) and the replicated plan + meta
+on rank 0.  Weak scaling (256 frames per GPU, `--frames 256`) has neither problem.
 """)
 
 out = ["| case | modes | centre px max / mean | corner px max / mean | 2x2 max | true motion px |", "|---|---|---|---|---|---|"]
