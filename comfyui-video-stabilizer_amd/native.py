@@ -591,10 +591,6 @@ class Context:
         warp_frames: frames the following warp_batch_planned(want_count=True) will warp -- its count array is allocated here
         and zeroed by the plan kernel, so that no fill launch sits between plan and warp."""
         self._planned_counts = None
-        if warp_frames:
-            self._planned_counts = self.torch.empty((int(warp_frames),), dtype=self.torch.int32, device=self.device)
-            _check(self.lib.vstab_flow_plan_zero_counts(self.handle, _dev_ptr(self._planned_counts), int(warp_frames)),
-                   "vstab_flow_plan_zero_counts")
         up = down = None
         if working_size is not None:
             sx, sy = working_size[0] / float(source_size[0]), working_size[1] / float(source_size[1])
@@ -602,6 +598,12 @@ class Context:
             down = np.array([sx, sy, 1.0], np.float64)
         seg = np.ascontiguousarray(seg_pairs, np.int32) if seg_pairs is not None else None
         self.use_torch_stream()
+        if warp_frames:
+            # registered right in front of the plan call, with every argument already built: the library hands the pointer to
+            # THAT call's kernel only (and drops it if the call is refused), so no stale registration can outlive the tensor
+            counts = self.torch.empty((int(warp_frames),), dtype=self.torch.int32, device=self.device)
+            _check(self.lib.vstab_flow_plan_zero_counts(self.handle, _dev_ptr(counts), int(warp_frames)), "vstab_flow_plan_zero_counts")
+            self._planned_counts = counts
         _check(self.lib.vstab_flow_plan_device(
             self.handle, C.c_void_p(int(records_ptr)), int(pairs), MODES[requested_mode],
             up.ctypes.data if up is not None else None, down.ctypes.data if down is not None else None,
