@@ -46,6 +46,7 @@ struct PlanArgs {
     double* target;                // [frames][p]
     double* region;                // [4]: x0, y0, x1, y1 of the common region (tests)
     int perturb;                   // tests (VSTAB_DEBUG_PLAN_PERTURB=frame): that frame's matrix is made wrong by one ulp
+    int framing;                   // 0: crop_and_pad (recentre on the frames' common region), 1: expand (shift the frames' union to the origin)
     unsigned* zero;                // the planned warp's padded-pixel counts: zeroed here (vstab_flow_plan_zero_counts), or nullptr
     int zero_n;
 };
@@ -62,12 +63,14 @@ __device__ __forceinline__ const vstab_fit_record* pair_records(const PlanArgs& 
 __device__ __forceinline__ double np_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
 __device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 
-// block-wide reduction of four doubles (max, max, min, min) with NumPy's NaN-propagating minimum / maximum
-__device__ void reduce_region(double v[4], double* s_red /*[4][PLAN_T / 64]*/)
+// block-wide reduction of four doubles with NumPy's NaN-propagating minimum / maximum: (max, max, min, min) -- the frames'
+// common region -- or, with `uni`, (min, min, max, max) -- their union (expand framing)
+__device__ void reduce_region(double v[4], double* s_red /*[4][PLAN_T / 64]*/, bool uni)
 {
     for (int off = 32; off > 0; off >>= 1) {
-        v[0] = np_max(v[0], __shfl_xor(v[0], off)); v[1] = np_max(v[1], __shfl_xor(v[1], off));
-        v[2] = np_min(v[2], __shfl_xor(v[2], off)); v[3] = np_min(v[3], __shfl_xor(v[3], off));
+        const double o0 = __shfl_xor(v[0], off), o1 = __shfl_xor(v[1], off), o2 = __shfl_xor(v[2], off), o3 = __shfl_xor(v[3], off);
+        v[0] = uni ? np_min(v[0], o0) : np_max(v[0], o0); v[1] = uni ? np_min(v[1], o1) : np_max(v[1], o1);
+        v[2] = uni ? np_max(v[2], o2) : np_min(v[2], o2); v[3] = uni ? np_max(v[3], o3) : np_min(v[3], o3);
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = PLAN_T / 64;
     if (lane == 0) for (int k = 0; k < 4; k++) s_red[k * nw + wave] = v[k];
@@ -75,7 +78,7 @@ __device__ void reduce_region(double v[4], double* s_red /*[4][PLAN_T / 64]*/)
     if (threadIdx.x == 0) {
         for (int k = 0; k < 4; k++) {
             double acc = s_red[k * nw];
-            for (int i = 1; i < nw; i++) acc = k < 2 ? np_max(acc, s_red[k * nw + i]) : np_min(acc, s_red[k * nw + i]);
+            for (int i = 1; i < nw; i++) acc = ((k < 2) != uni) ? np_max(acc, s_red[k * nw + i]) : np_min(acc, s_red[k * nw + i]);
             s_red[k * nw] = acc;
         }
     }
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     //      vstab_params_to_matrices / vstab_bounding_boxes on the host)
     const int pad = a.window / 2;
     const double kv = 1.0 / (double)a.window;
-    double reg[4] = {-INFINITY, -INFINITY, INFINITY, INFINITY};   // max of mins.x, mins.y; min of maxs.x, maxs.y
+    const bool uni = a.framing == 1;
+    // crop_and_pad: max of mins.x, mins.y; min of maxs.x, maxs.y (the common region).  expand: min of mins, max of maxs (the union)
+    double reg[4] = {uni ? INFINITY : -INFINITY, uni ? INFINITY : -INFINITY, uni ? -INFINITY : INFINITY, uni ? -INFINITY : INFINITY};
     float A[9];
     for (int i = threadIdx.x; i < frames; i += PLAN_T) {
         double diff[4];
@@ -226,16 +231,20 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
             xs[j] = q[0] / q[2];
             ys[j] = q[1] / q[2];
         }
-        reg[0] = np_max(reg[0], np_min(np_min(xs[0], xs[1]), np_min(xs[2], xs[3])));
-        reg[1] = np_max(reg[1], np_min(np_min(ys[0], ys[1]), np_min(ys[2], ys[3])));
-        reg[2] = np_min(reg[2], np_max(np_max(xs[0], xs[1]), np_max(xs[2], xs[3])));
-        reg[3] = np_min(reg[3], np_max(np_max(ys[0], ys[1]), np_max(ys[2], ys[3])));
+        const double mnx = np_min(np_min(xs[0], xs[1]), np_min(xs[2], xs[3])), mny = np_min(np_min(ys[0], ys[1]), np_min(ys[2], ys[3]));
+        const double mxx = np_max(np_max(xs[0], xs[1]), np_max(xs[2], xs[3])), mxy = np_max(np_max(ys[0], ys[1]), np_max(ys[2], ys[3]));
+        reg[0] = uni ? np_min(reg[0], mnx) : np_max(reg[0], mnx);
+        reg[1] = uni ? np_min(reg[1], mny) : np_max(reg[1], mny);
+        reg[2] = uni ? np_max(reg[2], mxx) : np_min(reg[2], mxx);
+        reg[3] = uni ? np_max(reg[3], mxy) : np_min(reg[3], mxy);
     }
-    // ---- common region over all frames -> recentring shift (flow.py:501-511), float32 like the reference's matrix
-    reduce_region(reg, s_red);
+    // ---- common region over all frames -> recentring shift (flow.py:501-511); or their union -> the shift that brings it to the
+    //      origin (stabilizer_utils.py:386-406, flow.py:530-533; the canvas size is the host's to form from `region`): float32
+    //      like the reference's matrix either way
+    reduce_region(reg, s_red, uni);
     if (threadIdx.x == 0) for (int k = 0; k < 4; k++) a.region[k] = reg[k];
-    const float off_x = (float)(a.width * 0.5 - (reg[0] + reg[2]) * 0.5);
-    const float off_y = (float)(a.height * 0.5 - (reg[1] + reg[3]) * 0.5);
+    const float off_x = uni ? (float)(-reg[0]) : (float)(a.width * 0.5 - (reg[0] + reg[2]) * 0.5);
+    const float off_y = uni ? (float)(-reg[1]) : (float)(a.height * 0.5 - (reg[1] + reg[3]) * 0.5);
     // ---- final = T @ A in float32 (A is affine: every sum has one inexact term), inverted into the warp's table
     for (int i = threadIdx.x; i < frames; i += PLAN_T) {
         float* Fm = a.final32 + (size_t)i * 9;
@@ -320,7 +329,7 @@ extern "C" int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int
 
 extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
                                       const double* up, const double* down, double smooth, double fps, double strength,
-                                      int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows)
+                                      int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows, int framing)
 {
     // a registered count array belongs to THIS call only, whether it succeeds or not (a refused call must not leave the
     // pointer behind for a later kernel to write through)
@@ -333,6 +342,7 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
                   "vstab_flow_plan_device: only translation / similarity plans are formed on the device (mode %d)", requested_mode);
     VSTAB_REQUIRE((up == nullptr) == (down == nullptr), "vstab_flow_plan_device: up and down come together");
     VSTAB_REQUIRE(width > 0 && height > 0, "vstab_flow_plan_device: non-positive frame size");
+    VSTAB_REQUIRE(framing == 0 || framing == 1, "vstab_flow_plan_device: framing %d (0 = crop_and_pad, 1 = expand; crop is the host's keep_fov solver)", framing);
     const int p = requested_mode == VSTAB_MODE_SIMILARITY ? 4 : 2, frames = pairs + 1;
     const size_t lds = sizeof(double) * ((size_t)frames * p + 4 * (PLAN_T / 64)) + (((size_t)pairs + 15) & ~size_t(15));
     VSTAB_REQUIRE(lds <= PLAN_LDS_MAX, "vstab_flow_plan_device: a clip of %d frames does not fit the plan kernel's LDS", frames);
@@ -374,6 +384,7 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     a.target = reinterpret_cast<double*>(base + L.target);
     a.region = reinterpret_cast<double*>(base + L.region);
     a.perturb = -1;
+    a.framing = framing;
     a.zero = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
     ctx->plan_zeroed_ptr = zero_ptr;
 #ifdef VSTAB_TEST_HOOKS   // fault injector of the test build (lib/libvstab_hooks.so); the shipped library reads no such variable

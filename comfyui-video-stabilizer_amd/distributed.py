@@ -393,6 +393,7 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
     gathered = torch.cuda.Event()
     gathered.record()
     own = local_frames[halo:]
+    out_size = size
     dst = torch.empty((0, size[1], size[0], 3), dtype=torch.float32, device=own.device)
     mask = torch.empty((0, size[1], size[0]), dtype=torch.float32, device=own.device)
     counts = torch.zeros((0,), dtype=torch.int32, device=own.device)
@@ -402,9 +403,15 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
             # (a peer that failed sent zero records: plan_kernel treats such pairs as "no fit" -- identity -- so the launches
             # below are harmless; this rank learns of the failure from the status rows a few lines down and raises)
             ctx.flow_plan_device(flat.data_ptr(), total_frames - 1, transform_mode, size, working_size, smooth, fps_effective, strength,
-                                 bool(camera_lock), seg_pairs=per_rank, seg_rows=rows + 1, warp_frames=n_local)
+                                 bool(camera_lock), seg_pairs=per_rank, seg_rows=rows + 1, warp_frames=n_local, framing=framing_mode)
+            if framing_mode == "expand":   # the canvas comes from the (replicated) plan kernel's region, see flow_pipeline
+                out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[3])
+                if out_size is None:
+                    raise native.VstabError("the device plan's expand region is not finite")
+                dst = torch.empty((0, out_size[1], out_size[0], 3), dtype=torch.float32, device=own.device)
+                mask = torch.empty((0, out_size[1], out_size[0]), dtype=torch.float32, device=own.device)
             if n_local > 0:
-                dst, mask, counts = ctx.warp_batch_planned(own, start, size, border=hm.border_value(padding_rgb), want_mask=True,
+                dst, mask, counts = ctx.warp_batch_planned(own, start, out_size, border=hm.border_value(padding_rgb), want_mask=True,
                                                            want_count=True)
             t0 = _lap(stats, "warp_launch", t0)
             if pairs_local:
@@ -424,7 +431,18 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
                                       keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
             t0 = _lap(stats, "plan", t0)
             final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
-            if n_local > 0:
+            if tuple(plan.output_size) != tuple(out_size):
+                # expand: the host's canvas differs from the device's by a pixel (an extent within one ulp of an integer) -- on every
+                # rank alike, the plan being replicated: this rank's frames are warped again onto the host plan's canvas
+                if n_local > 0:
+                    dst, mask, counts = ctx.warp_batch(own, np.ascontiguousarray(plan.final_matrices[start:start + n_local], np.float32),
+                                                       plan.output_size, interp="bilinear", border=hm.border_value(padding_rgb),
+                                                       want_mask=True, want_count=True)
+                else:
+                    dst = torch.empty((0, plan.output_size[1], plan.output_size[0], 3), dtype=torch.float32, device=own.device)
+                    mask = torch.empty((0, plan.output_size[1], plan.output_size[0]), dtype=torch.float32, device=own.device)
+                verdict["mismatched_frames"] = n_local
+            elif n_local > 0:
                 sub = _fp.FlowPlan(plan.final_matrices[start:start + n_local], plan.output_size, {}, {}, {}, plan.framing_mode, size, fps_effective)
                 verdict["mismatched_frames"] = _fp._rewarp_mismatched(ctx, own, sub, final_dev[start:start + n_local], dst, mask, counts,
                                                                       padding_rgb)

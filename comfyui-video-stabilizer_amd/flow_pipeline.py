@@ -460,7 +460,7 @@ def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, 
     What a call did is reported in its result (`StabilizationResult.device_plan`, `stats["device_plan"]` of a sharded call):
     {"used": bool, "mismatched_frames": int} -- there is no module-level record."""
     return (os.environ.get("VSTAB_DEVICE_PLAN", "1") not in ("0", "false", "False") and estimator == "flow"
-            and framing_mode == "crop_and_pad" and transform_mode in ("translation", "similarity")
+            and framing_mode in ("crop_and_pad", "expand") and transform_mode in ("translation", "similarity")
             and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES and 1 <= segments <= _DEVICE_PLAN_MAX_SEGMENTS)
 
 
@@ -500,8 +500,16 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
     _, grid = ctx.dis_flow_batch(gray, sample_step=SAMPLE_STEP, want_full=False, want_grid=True)
     pairs = ctx.sample_fit_batch_begin(grid, SAMPLE_STEP, transform_mode)
     ctx.flow_plan_device(ctx.fit_records_device(), pairs, transform_mode, size, working_size, smooth, fps_effective, strength,
-                         bool(camera_lock), warp_frames=total_frames)
-    dst, mask, counts = ctx.warp_batch_planned(device_frames, 0, size, border=hm.border_value(padding_rgb), want_mask=True,
+                         bool(camera_lock), warp_frames=total_frames, framing=framing_mode)
+    out_size = size
+    if framing_mode == "expand":
+        # the canvas has to exist before the warp is queued: wait for the plan kernel's region (the plan's download, ~30 us
+        # behind the fit kernel on the side stream -- not for the host's own plan, which runs under the warp as before)
+        out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[3])
+        if out_size is None:           # a non-finite region: nothing to speculate on
+            ctx.sample_fit_batch_end(pairs)
+            return None
+    dst, mask, counts = ctx.warp_batch_planned(device_frames, 0, out_size, border=hm.border_value(padding_rgb), want_mask=True,
                                                want_count=True)
     fit_records = ctx.sample_fit_batch_end(pairs)          # waits for the fits only; the plan kernel and the warp run on
     if peaks and hm.resolve_value_range(context, peaks[0], ctx):
@@ -512,11 +520,20 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
                               keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
     meta = prepare_meta(plan)                               # host JSON work overlaps the warp kernel
     final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
-    verdict = {"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb)}
+    if tuple(plan.output_size) != tuple(out_size):
+        # expand: the host's canvas is a pixel wider / taller than the device's (an extent within one ulp of an integer): every
+        # frame is warped again onto the host plan's canvas
+        dst, mask, counts = ctx.warp_batch(device_frames, plan.final_matrices, plan.output_size, interp="bilinear",
+                                           border=hm.border_value(padding_rgb), want_mask=True, want_count=True)
+        verdict = {"used": True, "mismatched_frames": total_frames}
+        mirror_ok = True               # (the counts of that one warp of all frames are what the library mirrored last)
+    else:
+        verdict = {"used": True, "mismatched_frames": _rewarp_mismatched(ctx, device_frames, plan, final_dev, dst, mask, counts, padding_rgb)}
+        mirror_ok = verdict["mismatched_frames"] == 0
     _replay_progress(pbar, progress_done, total_frames, progress_total)   # (host work that needs no pixel: before the last wait)
     # the warp's counts: mirrored to the host behind the kernel (native.last_pad_counts) -- unless frames were warped again,
     # whose counts went into the device tensor only
-    meta = complete_meta(meta, plan, _counts_to_host(counts, mirrored=verdict["mismatched_frames"] == 0))
+    meta = complete_meta(meta, plan, _counts_to_host(counts, mirrored=mirror_ok))
     check_interrupt()
     if keep_on_device:
         return hm.StabilizationResult(dst, mask.unsqueeze(-1), meta, verdict)

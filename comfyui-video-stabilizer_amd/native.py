@@ -143,7 +143,7 @@ _SIGNATURES = {
     "vstab_sample_fit_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vstab_flow_plan_device": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
-                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "vstab_fit_records_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vstab_flow_plan_result": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_warp_batch_planned": (
@@ -585,11 +585,15 @@ class Context:
         _check(self.lib.vstab_fit_records_copy(self.handle, _dev_ptr(dst), int(pairs)), "vstab_fit_records_copy")
 
     def flow_plan_device(self, records_ptr, pairs, requested_mode, source_size, working_size, smooth, fps, strength, camera_lock,
-                         seg_pairs=None, seg_rows=0, warp_frames=0):
+                         seg_pairs=None, seg_rows=0, warp_frames=0, framing="crop_and_pad"):
         """Queue plan_kernel behind the fits: records (device address) -> the warp's transform table, on the device.
         seg_pairs / seg_rows: the records are an all-gather's receive buffer (seg_rows pairs per rank, seg_pairs[r] valid).
         warp_frames: frames the following warp_batch_planned(want_count=True) will warp -- its count array is allocated here
-        and zeroed by the plan kernel, so that no fill launch sits between plan and warp."""
+        and zeroed by the plan kernel, so that no fill launch sits between plan and warp.
+        framing: "crop_and_pad" (matrices recentred on the frames' common region) or "expand" (shifted so that the frames'
+        union starts at the origin; the canvas size comes from flow_plan_result's region: expand_canvas())."""
+        if framing not in ("crop_and_pad", "expand"):
+            raise VstabError(f"flow_plan_device: framing {framing!r} is not formed on the device")
         self._planned_counts = None
         up = down = None
         if working_size is not None:
@@ -608,8 +612,20 @@ class Context:
             self.handle, C.c_void_p(int(records_ptr)), int(pairs), MODES[requested_mode],
             up.ctypes.data if up is not None else None, down.ctypes.data if down is not None else None,
             float(smooth), float(fps), float(strength), 1 if camera_lock else 0, int(source_size[0]), int(source_size[1]),
-            len(seg) if seg is not None else 0, seg.ctypes.data if seg is not None else None, int(seg_rows)),
+            len(seg) if seg is not None else 0, seg.ctypes.data if seg is not None else None, int(seg_rows),
+            1 if framing == "expand" else 0),
             "vstab_flow_plan_device")
+
+    @staticmethod
+    def expand_canvas(region):
+        """(width, height) of the expand canvas from the device plan's region x_min, y_min, x_max, y_max -- the arithmetic of
+        _prepare_expand_transform (stabilizer_utils.py:386-406); None if the region is not finite."""
+        import math
+
+        x0, y0, x1, y1 = (float(v) for v in region)
+        if not all(math.isfinite(v) for v in (x0, y0, x1, y1)):
+            return None
+        return max(int(math.ceil(x1 - x0)), 1), max(int(math.ceil(y1 - y0)), 1)
 
     def flow_plan_result(self, frames, params):
         """(final float32 matrices [frames,3,3], path, target [frames,params], region [4]) of the pending device plan."""

@@ -309,9 +309,13 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
 /* Optional, before vstab_flow_plan_device: the planned warp's padded-pixel count array (dev [n] u32); the plan kernel zeroes
  * it, and vstab_warp_batch_planned with the same pointer skips its own fill -- one launch less between plan and warp. */
 int vstab_flow_plan_zero_counts(vstab_ctx* ctx, uint32_t* pad_count, int n);
+/* framing (last argument of vstab_flow_plan_device): 0 = crop_and_pad -- `region` = the frames' common region, the matrices are
+ * recentred on it (flow.py:500-529); 1 = expand -- `region` = the frames' union x_min, y_min, x_max, y_max, the matrices are
+ * shifted by (-x_min, -y_min) (stabilizer_utils.py:386-406); the caller forms the canvas size ceil(x_max - x_min) x
+ * ceil(y_max - y_min) from vstab_flow_plan_result's region before it queues the warp. */
 int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_records, int pairs, int requested_mode,
                            const double* up, const double* down, double smooth, double fps, double strength,
-                           int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows);
+                           int camera_lock, int width, int height, int segments, const int* seg_pairs, int seg_rows, int framing);
 /* segments = 0: d_records is [pairs*3].  segments = world > 0 (multi-GPU): d_records is the receive buffer of the ranks'
  * all-gather as RCCL leaves it -- one block of seg_rows pairs per rank, of which the first seg_pairs[r] are valid -- so the
  * gathered table feeds the plan where it lands (no compaction pass, no host copy before the warp). */

@@ -105,21 +105,25 @@ def test_host_trajectory_tracks_the_plan_kernel_on_similarity_deltas(ctx, pkg):
             assert np.abs(host[:, col] - dev[:, col]).max() <= 16 * ulp, (col, np.abs(host[:, col] - dev[:, col]).max() / ulp)
 
 
-def _run(ctx, frames, mode, monkeypatch, device_plan):
+def _run(ctx, frames, mode, monkeypatch, device_plan, framing="crop_and_pad"):
     from vstab_amd import flow_pipeline as fp
     from vstab_amd import host_math as hm
 
     monkeypatch.setenv("VSTAB_DEVICE_PLAN", "1" if device_plan else "0")
-    res = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", mode, False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
+    res = fp._stabilize_frames(hm._normalize_video_input(frames), framing, mode, False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0,
                                ctx=ctx, keep_on_device=True)
     return res, res.device_plan   # what the speculation did travels in the result, not in module state
 
 
+@pytest.mark.parametrize("framing", ["crop_and_pad", "expand"])
 @pytest.mark.parametrize("mode", ["similarity", "translation"])
-def test_flow_node_is_the_same_with_and_without_the_device_plan(ctx, pkg, monkeypatch, mode):
+def test_flow_node_is_the_same_with_and_without_the_device_plan(ctx, pkg, monkeypatch, mode, framing):
+    """expand (round 5): the plan kernel shifts the frames' union to the origin and the host sizes the canvas from the kernel's
+    region before it queues the warp; same pixels, same canvas, same meta as the host-plan flow."""
     frames = _clip(ctx, 16, 1280, 720, "similarity", amp=1.5)
-    a, info_a = _run(ctx, frames, mode, monkeypatch, device_plan=False)
-    b, info_b = _run(ctx, frames, mode, monkeypatch, device_plan=True)
+    a, info_a = _run(ctx, frames, mode, monkeypatch, device_plan=False, framing=framing)
+    b, info_b = _run(ctx, frames, mode, monkeypatch, device_plan=True, framing=framing)
+    assert tuple(a.frames.shape) == tuple(b.frames.shape) and (framing == "crop_and_pad") == (tuple(a.frames.shape[1:3]) == (720, 1280))
     assert info_a == {"used": False, "mismatched_frames": 0} and info_b == {"used": True, "mismatched_frames": 0}
     assert a.meta == b.meta
     assert bool((a.frames == b.frames).all()) and bool((a.masks == b.masks).all())

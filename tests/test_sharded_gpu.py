@@ -111,20 +111,22 @@ def test_sharded_device_plan_under_rccl_equals_single_process(pkg, ctx, tmp_path
     assert json.loads((tmp_path / "meta_0.json").read_text()) == json.loads(json.dumps(ref.meta))
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 9), (3, 9), (3, 2)])
-def test_sharded_device_plan_with_several_ranks_equals_single_process(pkg, ctx, tmp_path, monkeypatch, world, n_frames):
+@pytest.mark.parametrize("world,n_frames,framing", [(2, 9, "crop_and_pad"), (3, 9, "crop_and_pad"), (3, 2, "crop_and_pad"),
+                                                    (2, 9, "expand"), (3, 2, "expand")])
+def test_sharded_device_plan_with_several_ranks_equals_single_process(pkg, ctx, tmp_path, monkeypatch, world, n_frames, framing):
     """The multi-rank layout of the device-plan form -- every rank's records into its row block of the gathered table,
     plan_kernel on that table through the segment table, each rank's warp from ITS slice of the device plan, the host plan's
-    verification of that slice, a rank without frames (3 ranks, 2 frames) -- with real ranks on the one GPU
+    verification of that slice, a rank without frames (3 ranks, 2 frames), the expand framing (every rank sizes the canvas from
+    its own copy of the plan kernel's region) -- with real ranks on the one GPU
     (VSTAB_SHARDED_DEVICE_PLAN=force: gloo control plane, the collectives through the host).  Equal to the single-process
     node bit for bit on every rank."""
     from vstab_amd import flow_pipeline as fp
     from vstab_amd import host_math as hm
 
     monkeypatch.setenv("VSTAB_SHARDED_DEVICE_PLAN", "force")
-    _spawn(world, tmp_path, "flow", "crop_and_pad", 0.6, n_frames)
+    _spawn(world, tmp_path, "flow", framing, 0.6, n_frames)
     frames = _clip()[:n_frames]
-    ref = fp._stabilize_frames(hm._normalize_video_input(frames), "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
+    ref = fp._stabilize_frames(hm._normalize_video_input(frames), framing, "similarity", False, 0.7, 0.5, 0.6, (127, 127, 127), 16.0)
     dst = np.concatenate([np.load(tmp_path / f"dst_{r}.npy") for r in range(world)])
     mask = np.concatenate([np.load(tmp_path / f"mask_{r}.npy") for r in range(world)])
     assert np.array_equal(dst, ref.frames) and np.array_equal(mask, ref.masks[..., 0])
