@@ -221,8 +221,16 @@ __global__ __launch_bounds__(256) void area_general_rows_kernel(const uint8_t* _
 // per workgroup, as in area_general_rows_kernel) and written to both LDS and its plane.  Per output the same taps, the same
 // f32 sums in the same order as area_u8_kernel's modes 0 / 1 / 2 (whichever launch_area would pick for that level).
 constexpr int TAIL_MAX_LEVELS = 8;
+#ifdef VSTAB_FUSED_TRACE
+#define TAIL_MARK(i) do { if (prof_) { const long long now_ = wall_clock64(); a.dbg[i] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define TAIL_MARK(i)
+#endif
 struct TailLevel { uint8_t* dst; int h, w, mode, kx, ky; double scale_x, scale_y; };
 struct TailArgs {
+#ifdef VSTAB_FUSED_TRACE
+    long long* dbg;
+#endif
     const uint8_t* src;   // [n][h0][w0]: the finest level
     int n, h0, w0, levels;
     TailLevel lv[TAIL_MAX_LEVELS];
@@ -236,10 +244,16 @@ struct TailArgs {
     int prep_ws, prep_hs, prep_lds_off;   // patch grid of the coarsest level; byte offset of the preparation's LDS scratch
 };
 
-__global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
+// 1024 threads: the phases are chains of LDS round trips; with four wavefronts on a CU (one per SIMD) every instruction's latency was
+// exposed (level 3 alone 25 us), with sixteen they overlap.
+__global__ __launch_bounds__(1024) void pyramid_tail_kernel(TailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
     const int f = blockIdx.x;
+#ifdef VSTAB_FUSED_TRACE
+    long long tprev_ = wall_clock64();
+    const bool prof_ = a.dbg && blockIdx.x == 7 && threadIdx.x == 0;
+#endif
     const int cap0 = (a.h0 * a.w0 + 15) & ~15;                // level images ping-pong between two buffers
     const int cap1 = (a.lv[0].h * a.lv[0].w + 15) & ~15;
     unsigned char* bufA = tail_lds;
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
         }
     }
     __syncthreads();
+    TAIL_MARK(0);
     int sh = a.h0, sw = a.w0;
     unsigned char* cur = bufA;
     unsigned char* nxt = bufB;
@@ -329,6 +344,7 @@ __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
             D[t] = (uint8_t)o;
         }
         __syncthreads();
+        TAIL_MARK(1 + l);
         unsigned char* tmp = cur; cur = nxt; nxt = tmp;
         sh = dh; sw = dw;
     }
@@ -399,6 +415,10 @@ __global__ __launch_bounds__(256) void pyramid_tail_kernel(TailArgs a)
                 }
             }
         }
+#ifdef VSTAB_FUSED_TRACE
+        __syncthreads();
+#endif
+        TAIL_MARK(6);
     }
 }
 
@@ -1641,6 +1661,9 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
         }
         if (tail_on && tail_levels >= 1 && tail_levels <= TAIL_MAX_LEVELS && tail_lds <= 150 * 1024) {
             TailArgs ta{};
+#ifdef VSTAB_FUSED_TRACE
+            ta.dbg = g_dis_dbg ? g_dis_dbg + 16 * 7 : nullptr;
+#endif
             {   // the coarsest level's preparation rides along where its scratch fits too
                 const LevelGeom& c = G[coarsest];
                 const size_t off = (tail_lds + 15) & ~size_t(15);
@@ -1665,7 +1688,7 @@ static int dis_run(vstab_ctx* ctx, const uint8_t* gray, int n, int h, int w, int
             }
             if (tail_lds > 64 * 1024)
                 VSTAB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-            hipLaunchKernelGGL(pyramid_tail_kernel, dim3((unsigned)n), dim3(256), tail_lds, st, ta);
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3((unsigned)n), dim3(1024), tail_lds, st, ta);
             VSTAB_HIP(hipGetLastError());
         } else {
             for (int i = FINEST + 1; i <= coarsest; i++)

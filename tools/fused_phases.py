@@ -28,3 +28,6 @@ for rep in range(2):
     for lvl in range(8):
         if d[lvl].sum() > 0:
             print(" level", lvl, "total us %.0f:" % d[lvl, :9].sum(), ", ".join(f"{n} {v:.0f}" for n, v in zip(names, d[lvl, :9])))
+    t = d[7]
+    if t.sum() > 0:
+        print(" pyramid tail us: load %.0f, levels %s, coarsest prep %.0f" % (t[0], [round(float(v)) for v in t[1:6] if v > 0], t[6]))
