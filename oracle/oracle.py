@@ -251,6 +251,39 @@ def dis_flow(i0, i1, params=None):
     return flow
 
 
+def dis_patch_search(i0, i1, u0=None, v0=None, params=None):
+    """The patch inverse search of ONE level (test-only view): level images i0 / i1 [h,w] u8, dense initial flow (default 0)
+    -> sparse flow (sx, sy) [hs,ws] of the 8x8 patches at stride 4."""
+    i0 = np.ascontiguousarray(i0, np.uint8)
+    i1 = np.ascontiguousarray(i1, np.uint8)
+    h, w = i0.shape
+    p = params or dis_params()
+    u0 = np.zeros((h, w), np.float32) if u0 is None else np.ascontiguousarray(u0, np.float32)
+    v0 = np.zeros((h, w), np.float32) if v0 is None else np.ascontiguousarray(v0, np.float32)
+    hs, ws = 1 + (h - p.patch_size) // p.patch_stride, 1 + (w - p.patch_size) // p.patch_stride
+    sx, sy = np.zeros((hs, ws), np.float32), np.zeros((hs, ws), np.float32)
+    rc = lib().vo_dis_patch_search_debug(_ptr(i0, C.c_uint8), _ptr(i1, C.c_uint8), h, w, _ptr(u0, C.c_float), _ptr(v0, C.c_float),
+                                         _ptr(sx, C.c_float), _ptr(sy, C.c_float), C.byref(p))
+    if rc != 0:
+        raise ValueError("vo_dis_patch_search_debug: bad arguments")
+    return sx, sy
+
+
+def variational_refine(i0, i1, u, v, params=None, sor_iters=5):
+    """The variational refinement (OpenCV's VariationalRefinement::calcUV as DIS configures it) of flow (u, v) on one level
+    (test-only view): returns the refined (u, v).  sor_iters: SOR iterations per fixed-point iteration (DIS uses 5)."""
+    i0 = np.ascontiguousarray(i0, np.uint8)
+    i1 = np.ascontiguousarray(i1, np.uint8)
+    h, w = i0.shape
+    uu, vv = np.array(u, np.float32, copy=True, order="C"), np.array(v, np.float32, copy=True, order="C")
+    p = params or dis_params()
+    rc = lib().vo_variational_refine_debug(_ptr(i0, C.c_uint8), _ptr(i1, C.c_uint8), h, w, _ptr(uu, C.c_float), _ptr(vv, C.c_float),
+                                           C.byref(p), int(sor_iters))
+    if rc != 0:
+        raise ValueError("vo_variational_refine_debug: bad arguments")
+    return uu, vv
+
+
 def dis_gradients(img, patch_size=8, patch_stride=4):
     """Sobel gradients (s16) and structure-tensor planes [5,hs,ws] of one DIS level image (test-only view)."""
     img = np.ascontiguousarray(img, np.uint8)

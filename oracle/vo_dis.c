@@ -466,11 +466,11 @@ static void densify(const Level* L0, const Level* L1, const float* Sx, const flo
 /* ---------------- variational refinement (calcUV) ---------------- */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-static void variational_refine(const uint8_t* I0, const uint8_t* I1, int h, int w, float* U, float* V,
-                               const vo_dis_params* p)
+static void variational_refine_n(const uint8_t* I0, const uint8_t* I1, int h, int w, float* U, float* V,
+                                 const vo_dis_params* p, int sor_iters)
 {
     const size_t np = (size_t)h * w;
-    const int fixed_iters = p->var_iter, sor_iters = 5;
+    const int fixed_iters = p->var_iter;
     const float omega = 1.6f, zeta = 0.1f, epsilon = 0.001f;
     const float zeta_squared = zeta * zeta, epsilon_squared = epsilon * epsilon;
     const float gamma2 = p->gamma / 2, delta2 = p->delta / 2, alpha2 = p->alpha / 4;
@@ -606,6 +606,53 @@ static void variational_refine(const uint8_t* I0, const uint8_t* I1, int h, int 
     memcpy(U, tU, sizeof(float) * np);
     memcpy(V, tV, sizeof(float) * np);
     free(buf);
+}
+
+/* Test-only view (tests/test_referee_cpu.py): the patch inverse search of ONE level -- I0 / I1 are the level images, Ux / Uy the
+ * dense initial flow [h][w] (what the coarser level handed down), Sx / Sy receive the sparse flow [hs][ws] of the patch grid. */
+int vo_dis_patch_search_debug(const uint8_t* I0, const uint8_t* I1, int h, int w, const float* Ux, const float* Uy, float* Sx, float* Sy,
+                              const vo_dis_params* p)
+{
+    if (!I0 || !I1 || !Ux || !Uy || !Sx || !Sy || !p || p->patch_size != 8 || h < 8 || w < 8) return 1;
+    Level L0, L1;
+    memset(&L0, 0, sizeof(L0));
+    memset(&L1, 0, sizeof(L1));
+    const int psz = p->patch_size, pstr = p->patch_stride;
+    L0.w = L1.w = w; L0.h = L1.h = h;
+    L0.ws = L1.ws = 1 + (w - psz) / pstr;
+    L0.hs = L1.hs = 1 + (h - psz) / pstr;
+    const size_t np = (size_t)h * w, ns = (size_t)L0.ws * L0.hs;
+    L0.I = (uint8_t*)malloc(np); memcpy(L0.I, I0, np);
+    L0.Ix = (short*)malloc(sizeof(short) * np); L0.Iy = (short*)malloc(sizeof(short) * np);
+    sobel_s16(I0, h, w, L0.Ix, L0.Iy);
+    L0.xx = (float*)malloc(sizeof(float) * ns); L0.yy = (float*)malloc(sizeof(float) * ns); L0.xy = (float*)malloc(sizeof(float) * ns);
+    L0.sx = (float*)malloc(sizeof(float) * ns); L0.sy = (float*)malloc(sizeof(float) * ns);
+    structure_tensor(&L0, psz, pstr);
+    L1.I = (uint8_t*)malloc(np); memcpy(L1.I, I1, np);
+    L1.Iext = (uint8_t*)malloc((size_t)(h + 2 * DIS_BORDER) * (w + 2 * DIS_BORDER));
+    pad_replicate(I1, h, w, DIS_BORDER, L1.Iext);
+    patch_inverse_search(&L0, &L1, Ux, Uy, Sx, Sy, p);
+    level_free(&L0);
+    level_free(&L1);
+    return 0;
+}
+
+/* DIS runs OpenCV's VariationalRefinement with five SOR iterations per fixed-point iteration (dis_flow.cpp) */
+static void variational_refine(const uint8_t* I0, const uint8_t* I1, int h, int w, float* U, float* V,
+                               const vo_dis_params* p)
+{
+    variational_refine_n(I0, I1, h, w, U, V, p, 5);
+}
+
+/* Test-only view (tests/test_referee_cpu.py): the refinement of a given flow on ONE level with a chosen number of SOR
+ * iterations -- with one fixed-point iteration and many sweeps the increment converges to the exact solution of that
+ * iteration's linear system, which an independent sparse direct solve can referee. */
+int vo_variational_refine_debug(const uint8_t* I0, const uint8_t* I1, int h, int w, float* U, float* V,
+                                const vo_dis_params* p, int sor_iters)
+{
+    if (!I0 || !I1 || !U || !V || !p || h < 2 || w < 2 || sor_iters < 1) return 1;
+    variational_refine_n(I0, I1, h, w, U, V, p, sor_iters);
+    return 0;
 }
 
 /* flow between two prepared frames; L0 needs gradients, L1 needs Iext */

