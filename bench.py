@@ -40,7 +40,9 @@ Also on the JSON line (rank 0):
                  same 256 frames: matrices, confidences, every output pixel, every mask pixel, padding statistics
   batch_invariance (N = 1) pairs {0,127,254} re-run as 2-frame clips and frames {0,127,255} warped alone == the clip run
   c4, c5         (N > 1; c5 also with --force-dist) BASELINE configs[3] / configs[4] on the same ranks, outside the timed loop
-  host_roundtrip the node as ComfyUI calls it: CPU tensor in -> CPU tensors out (PCIe-inclusive; never `value`)
+  host_roundtrip the node as ComfyUI calls it: CPU tensor in -> CPU tensors out (PCIe-inclusive; never `value`);
+                 host_roundtrip_8bit_source: the same with the clip quantised to float32(k) / 255, what an IMAGE decoded from
+                 8-bit video holds (such chunks cross PCIe as bytes)
   motion_apply   Motion Apply rates for C3 (1080p, bicubic, blur 0.5, S=17) and C5's per-GPU share (4K, bilinear,
                  blur 0.5, S=33), device-resident (N = 1 only; measured outside the timed loop)
   config.rank0_host_ms   (N > 1) host wall-clock per phase of rank 0's step: the gathers and plan+meta are the
@@ -438,9 +440,18 @@ def measure_host_roundtrip(nodes, frames_host, repeats: int = 2) -> dict:
         best = dt if best is None else min(best, dt)
     n = frames_host.shape[0]
     gb = frames_host.numel() * 4 / 1e9
+    from vstab_amd import native
+
+    c = native.default_context()
+    coded_in, chunks_in = getattr(c, "last_upload_coded", (0, 0))
+    mask_coded = bool(getattr(c, "last_download_coded", False))
+    pcie_in = gb * (1.0 - 0.75 * coded_in / max(chunks_in, 1))
+    pcie_out = gb + gb / 3 * (0.25 if mask_coded else 1.0)
     return {"ms": round(best * 1e3, 1), "frames_per_s": round(n / best, 1), "frames": n,
             "pinned_output": os.environ.get("VSTAB_PINNED_OUTPUT", "0") not in ("", "0", "false", "False"),
             "bytes_in_GB": round(gb, 2), "bytes_out_GB": round(gb * 4 / 3, 2),
+            "pcie_in_GB": round(pcie_in, 2), "pcie_out_GB": round(pcie_out, 2),
+            "upload_chunks_as_bytes": [coded_in, chunks_in], "mask_as_bytes": mask_coded,
             "note": "CPU tensor in -> Video Stabilizer Flow node -> CPU tensors out, best of %d" % repeats}
 
 
@@ -951,6 +962,10 @@ def main() -> int:
                 try:
                     host = frames.cpu()
                     line["host_roundtrip"] = measure_host_roundtrip(nodes, host)
+                    # the same clip as a ComfyUI IMAGE decoded from 8-bit video holds it: float32(k) / 255 (the clip crosses PCIe
+                    # as bytes: vstab_upload_f32_coded)
+                    host.mul_(255.0).round_().clamp_(0.0, 255.0).div_(255.0)
+                    line["host_roundtrip_8bit_source"] = measure_host_roundtrip(nodes, host)
                     del host
                     del frames, step
                     torch.cuda.empty_cache()

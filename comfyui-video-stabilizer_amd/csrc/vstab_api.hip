@@ -168,6 +168,7 @@ int vstab_destroy(vstab_ctx* ctx)
     for (auto& ev : ctx->ev_xfer) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_xfer_sync) (void)hipEventDestroy(ctx->ev_xfer_sync);
     ctx->h_xfer.release();
+    ctx->d_xfer.release();
     if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
     for (auto& ev : ctx->ev_prep) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_pyramid) (void)hipEventDestroy(ctx->ev_pyramid);

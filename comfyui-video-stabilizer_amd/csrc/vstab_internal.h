@@ -83,6 +83,7 @@ struct vstab_ctx {
     unsigned counts_gen = 0;
     // bulk host <-> device transfers (vstab_xfer.hip): pinned ring, its events, a copy stream
     ScratchBuf h_xfer;
+    ScratchBuf d_xfer;   // device side of the coded forms: landing slots of byte-coded upload chunks / the packed mask
     hipEvent_t ev_xfer[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_xfer_sync = nullptr;
     hipStream_t xfer_stream = nullptr;
@@ -109,7 +110,7 @@ struct vstab_ctx {
     hipEvent_t ev_pyramid = nullptr;
 };
 
-enum { VSTAB_PEAKS_DONE_WORD = 4, VSTAB_COUNTS_DONE_WORD = 5 };      // index into h_status / d_status (the status word itself is [0])
+enum { VSTAB_PEAKS_DONE_WORD = 4, VSTAB_COUNTS_DONE_WORD = 5, VSTAB_XFER_OTHER_WORD = 6 };      // index into h_status / d_status (the status word itself is [0])
 enum { VSTAB_STATUS_PIS_TIMEOUT = 1 };   // DIS patch search: a bounded intra-workgroup dependency wait expired
 
 // Call after a host synchronisation of ctx->stream: turns a device-side failure report into a non-zero return

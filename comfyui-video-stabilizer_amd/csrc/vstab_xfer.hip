@@ -1,4 +1,5 @@
-// vstab_xfer.hip -- bulk host <-> device transfer for the node boundary (host code only, no kernels).
+// vstab_xfer.hip -- bulk host <-> device transfer for the node boundary (host code + the two byte <-> float kernels of the
+// coded forms at the end of the file).
 //
 // ComfyUI hands the nodes CPU tensors and expects CPU tensors back (nodes/stabilizer_utils.py:200-221): a 256 x 1080p
 // clip is 6.37 GB in and 8.49 GB out, against ~10 ms of GPU work.  The caller's tensors are ordinary pageable memory;
@@ -104,10 +105,17 @@ struct Team {
     {
         if (members > 1) pthread_barrier_wait(&bar);
     }
+    // this member's share [lo, hi) of `units` items, in 64-item steps
+    void share(int me, size_t units, size_t& lo, size_t& hi) const
+    {
+        const size_t part = (((units + members - 1) / members) + 63) & ~size_t(63);   // ceil: a tail shorter than the team is still covered
+        lo = std::min(units, part * me);
+        hi = std::min(units, part * (me + 1));
+    }
     void copy_share(int me, char* dst, const char* src, size_t bytes) const
     {
-        const size_t part = (((bytes + members - 1) / members) + 63) & ~size_t(63);   // ceil: a tail shorter than the team is still copied
-        const size_t lo = std::min(bytes, part * me), hi = std::min(bytes, part * (me + 1));
+        size_t lo, hi;
+        share(me, bytes, lo, hi);
         if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
     }
 };
@@ -224,4 +232,206 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
     team.run(bytes < (size_t(4) << 20) ? 1 : xfer_threads(), body);
     VSTAB_REQUIRE(!team.failed, "vstab_download: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
     return vstab_check_device_status(ctx, "vstab_download");
+}
+
+// ---- coded forms ---------------------------------------------------------------------------------------------------
+// Both directions of the node boundary are PCIe-bound (55 GB/s against ~7 ms of GPU work per 256 x 1080p clip), so bytes
+// that need not cross do not:
+//  * a ComfyUI IMAGE decoded from 8-bit video holds float32(k) / float32(255), k = 0 .. 255, and nothing else
+//    (`np.array(img).astype(np.float32) / 255.0`).  The staging threads look at every value they copy anyway: a chunk whose
+//    values ALL have exactly the bits of such a quotient crosses as bytes (a quarter of the traffic) and is expanded by
+//    a kernel with the same correctly rounded float32 division; any other chunk crosses as float32, and after the first such
+//    chunk the call stops trying.  The device tensor has the source's bits either way.
+//  * the Flow node's padding mask is 0.0f or 1.0f per pixel (nodes/video_stabilizer_flow.py:583-586): a kernel packs it
+//    to bytes and reports whether every value was one of the two; if so the bytes cross and the host threads expand
+//    them, else (Motion Apply's soft mask under motion blur) the plain download runs.
+// vstab_codec.cpp (host loops, baseline + AVX2 builds of the same source):
+// values -> bytes; false (output unspecified) unless every value has exactly the bits of float32(k) / 255.0f, k = 0 .. 255
+extern "C" bool vstab_host_encode_q8(const float* src, unsigned char* dst, size_t n);
+// bytes -> 0.0f / 1.0f
+extern "C" void vstab_host_expand_mask(const unsigned char* src, float* dst, size_t n);
+
+namespace {
+
+constexpr size_t QCHUNK = CHUNK;   // values per coded chunk: its byte form fills one ring slot (128 MB of float32 per chunk)
+
+__global__ __launch_bounds__(256) void expand_q8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+    const size_t vec = n / 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vec; i += stride) {
+        const uint4 q = reinterpret_cast<const uint4*>(src)[i];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+        float4* o = reinterpret_cast<float4*>(dst) + 4 * i;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            o[j] = make_float4((float)(w[j] & 255u) / 255.0f, (float)((w[j] >> 8) & 255u) / 255.0f,
+                               (float)((w[j] >> 16) & 255u) / 255.0f, (float)(w[j] >> 24) / 255.0f);
+    }
+    for (size_t i = vec * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i] / 255.0f;
+}
+
+// mask values -> bytes (0 / 1); *other is raised if a value is neither 0.0f nor 1.0f (by its bits: -0.0f counts as other)
+__global__ __launch_bounds__(256) void pack_mask_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t n, int* other)
+{
+    const size_t vec = n / 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned odd = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vec; i += stride) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 f = reinterpret_cast<const uint4*>(src)[4 * i + j];
+            const unsigned b[4] = {f.x, f.y, f.z, f.w};
+            unsigned pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                odd |= (b[k] != 0u) & (b[k] != 0x3f800000u);
+                pack |= (b[k] != 0u ? 1u : 0u) << (8 * k);
+            }
+            w[j] = pack;
+        }
+        reinterpret_cast<uint4*>(dst)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    for (size_t i = vec * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned b = reinterpret_cast<const unsigned*>(src)[i];
+        odd |= (b != 0u) & (b != 0x3f800000u);
+        dst[i] = b != 0u;
+    }
+    if (__ballot(odd != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(other, 1);
+}
+
+unsigned grid_for(size_t items16)
+{
+    const size_t blocks = (items16 + 255) / 256;
+    return (unsigned)std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 16);
+}
+
+}  // namespace
+
+extern "C" int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_upload_f32_coded: ctx is NULL");
+    VSTAB_REQUIRE(count == 0 || (host_src && dev_dst), "vstab_upload_f32_coded: NULL pointer argument");
+    if (coded_chunks) *coded_chunks = 0;
+    if (count == 0) return 0;
+    VSTAB_REQUIRE((reinterpret_cast<uintptr_t>(dev_dst) & 15) == 0, "vstab_upload_f32_coded: dev_dst must be 16-byte aligned");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    Ring r;
+    if (ring_get(ctx, r)) return 1;
+    if (ctx->d_xfer.reserve(QCHUNK * SLOTS)) return 1;        // the coded chunks' landing slots on the device
+    unsigned char* dslot = static_cast<unsigned char*>(ctx->d_xfer.ptr);
+    if (!ctx->ev_xfer_sync) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_xfer_sync, hipEventDisableTiming));
+    VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->stream));                 // as vstab_upload: dev_dst may still be in use on the stream
+    VSTAB_HIP(hipStreamWaitEvent(ctx->xfer_stream, ctx->ev_xfer_sync, 0));
+    const size_t chunks = (count + QCHUNK - 1) / QCHUNK;
+    size_t coded = 0;                                         // written by member 0 only, read after the team has finished
+    {
+        Team team;
+        std::atomic<int> chunk_bad[2];
+        chunk_bad[0] = chunk_bad[1] = 0;
+        auto body = [&](int me) {
+            for (size_t c = 0; c < chunks; c++) {
+                const int s = (int)(c % SLOTS);
+                const size_t off = c * QCHUNK, len = std::min(QCHUNK, count - off);
+                if (me == 0 && hipEventSynchronize(r.done[s]) != hipSuccess) team.failed = 1;   // the DMA that last read this slot
+                team.sync();
+                size_t lo, hi;
+                team.share(me, len, lo, hi);
+                if (hi > lo && !vstab_host_encode_q8(host_src + off + lo, reinterpret_cast<unsigned char*>(r.slot[s]) + lo, hi - lo)) chunk_bad[c & 1] = 1;
+                team.sync();
+                if (chunk_bad[c & 1] != 0 || team.failed) return;   // every member takes the same decision from the same flags
+                if (me == 0) {
+                    chunk_bad[(c + 1) & 1] = 0;               // nobody touches it before the next chunk's first barrier
+                    hipError_t e = hipMemcpyAsync(dslot + (size_t)s * QCHUNK, r.slot[s], len, hipMemcpyHostToDevice, ctx->xfer_stream);
+                    if (e == hipSuccess) e = hipEventRecord(r.done[s], ctx->xfer_stream);
+                    if (e == hipSuccess) {
+                        // (the next copy into this device slot is queued behind the kernel on the same stream)
+                        hipLaunchKernelGGL(expand_q8_kernel, dim3(grid_for(len / 16)), dim3(256), 0, ctx->xfer_stream,
+                                           dslot + (size_t)s * QCHUNK, dev_dst + off, len);
+                        e = hipGetLastError();
+                    }
+                    if (e != hipSuccess) team.failed = 1;     // (seen by the others at the next chunk's second barrier at the latest)
+                    else coded = c + 1;
+                }
+            }
+        };
+        team.run(count * sizeof(float) < (size_t(4) << 20) ? 1 : xfer_threads(), body);
+        VSTAB_REQUIRE(!team.failed, "vstab_upload_f32_coded: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    // the last chunk's expansion is the last thing on the copy stream: later work on the context's stream waits for it
+    VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->xfer_stream));
+    VSTAB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_xfer_sync, 0));
+    if (coded_chunks) *coded_chunks = coded;
+    // a chunk with a value of another kind: it and everything behind it cross as float32 (the ring's slots are guarded by their events)
+    const size_t done = coded * QCHUNK;
+    if (done < count) return vstab_upload(ctx, host_src + done, dev_dst + done, (count - done) * sizeof(float));
+    return 0;
+}
+
+extern "C" int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_download_mask_coded: ctx is NULL");
+    VSTAB_REQUIRE(count == 0 || (dev_src && host_dst), "vstab_download_mask_coded: NULL pointer argument");
+    if (coded) *coded = 0;
+    if (count == 0) return 0;
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    const bool aligned = (reinterpret_cast<uintptr_t>(dev_src) & 15) == 0;
+    if (!aligned || count < (size_t(1) << 20)) return vstab_download(ctx, dev_src, host_dst, count * sizeof(float));
+    Ring r;
+    if (ring_get(ctx, r)) return 1;
+    const size_t packed_bytes = (count + 15) & ~size_t(15);
+    if (ctx->d_xfer.reserve(packed_bytes + 16)) return 1;
+    unsigned char* packed = static_cast<unsigned char*>(ctx->d_xfer.ptr);
+    volatile int* other = ctx->h_status + VSTAB_XFER_OTHER_WORD;   // coherent host word, device-visible
+    int* d_other = ctx->d_status + VSTAB_XFER_OTHER_WORD;
+    // d_xfer may still be the source of an upload's expansion on the copy stream: the pack kernel runs behind it
+    if (!ctx->ev_xfer_sync) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_xfer_sync, hipEventDisableTiming));
+    VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->xfer_stream));
+    VSTAB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_xfer_sync, 0));
+    *other = 0;
+    hipLaunchKernelGGL(pack_mask_kernel, dim3(grid_for(count / 16)), dim3(256), 0, ctx->stream, dev_src, packed, count, d_other);
+    VSTAB_HIP(hipGetLastError());
+    VSTAB_HIP(hipStreamSynchronize(ctx->stream));
+    if (vstab_check_device_status(ctx, "vstab_download_mask_coded")) return 3;
+    if (*other != 0) return vstab_download(ctx, dev_src, host_dst, count * sizeof(float));
+    // the bytes through the ring, expanded by the team: one ring slot of bytes becomes four slots' worth of floats
+    const size_t chunks = (count + CHUNK - 1) / CHUNK;
+    Team team;
+    if (!(getenv("VSTAB_XFER_THP") && atoi(getenv("VSTAB_XFER_THP")) == 0)) {
+        const uintptr_t huge = uintptr_t(2) << 20;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(host_dst) + huge - 1) & ~(huge - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(host_dst) + count * sizeof(float)) & ~(huge - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    auto issue = [&](size_t c) {
+        const int s = (int)(c % SLOTS);
+        const size_t off = c * CHUNK, len = std::min(CHUNK, count - off);
+        if (hipMemcpyAsync(r.slot[s], packed + off, len, hipMemcpyDeviceToHost, ctx->xfer_stream) != hipSuccess ||
+            hipEventRecord(r.done[s], ctx->xfer_stream) != hipSuccess)
+            team.failed = 1;
+    };
+    const size_t ahead = std::min<size_t>(SLOTS - 1, chunks);
+    for (size_t c = 0; c < ahead; c++) issue(c);
+    auto body = [&](int me) {
+        for (size_t c = 0; c < chunks; c++) {
+            const int s = (int)(c % SLOTS);
+            const size_t off = c * CHUNK, len = std::min(CHUNK, count - off);
+            if (me == 0) {
+                if (hipEventSynchronize(r.done[s]) != hipSuccess) team.failed = 1;
+                if (c + ahead < chunks) issue(c + ahead);
+            }
+            team.sync();
+            if (!team.failed) {
+                size_t lo, hi;
+                team.share(me, len, lo, hi);
+                if (hi > lo) vstab_host_expand_mask(reinterpret_cast<const unsigned char*>(r.slot[s]) + lo, host_dst + off + lo, hi - lo);
+            }
+            team.sync();
+        }
+    };
+    team.run(xfer_threads(), body);
+    VSTAB_REQUIRE(!team.failed, "vstab_download_mask_coded: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    if (coded) *coded = 1;
+    return 0;
 }

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "vstab_kernel_ms_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "vstab_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vstab_upload_f32_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vstab_download_mask_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "vstab_warp_batch": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -278,6 +280,10 @@ def _check(rc: int, what: str) -> None:
         raise VstabError(f"{what} failed ({rc}): {msg.decode('utf-8', 'replace') if msg else 'unknown error'}")
 
 
+def _coded_transfers():
+    return os.environ.get("VSTAB_XFER_CODED", "1") not in ("0", "false", "False")
+
+
 def _dev_ptr(t) -> int:
     return int(t.data_ptr())
 
@@ -374,21 +380,38 @@ class Context:
 
     # ------------------------------------------------------------------ node-boundary transfers
     def upload(self, host_tensor):
-        """CPU tensor (pageable) -> new device tensor through the library's pinned ring (vstab_upload)."""
+        """CPU tensor (pageable) -> new device tensor through the library's pinned ring.  float32 tensors take
+        vstab_upload_f32_coded: chunks that hold nothing but float32(k) / 255 -- a ComfyUI IMAGE decoded from 8-bit video --
+        cross PCIe as bytes and are expanded on the device to the same bits (VSTAB_XFER_CODED=0: always as float32).
+        `last_upload_coded` = (chunks that crossed as bytes, chunks) of the most recent call."""
         torch = self.torch
         src = host_tensor.contiguous()
         dst = torch.empty(src.shape, dtype=src.dtype, device=self.device)
         self.use_torch_stream()
-        _check(self.lib.vstab_upload(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel() * src.element_size()), "vstab_upload")
+        if src.dtype == torch.float32 and _coded_transfers():
+            coded = C.c_size_t(0)
+            _check(self.lib.vstab_upload_f32_coded(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel(), C.byref(coded)), "vstab_upload_f32_coded")
+            self.last_upload_coded = (int(coded.value), -(-src.numel() // (32 << 20)))
+        else:
+            _check(self.lib.vstab_upload(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel() * src.element_size()), "vstab_upload")
+            self.last_upload_coded = (0, -(-src.numel() // (32 << 20)))
         return dst
 
-    def download(self, device_tensor):
-        """Device tensor -> new CPU tensor (pageable, as the reference returns) through the pinned ring (vstab_download)."""
+    def download(self, device_tensor, mask=False):
+        """Device tensor -> new CPU tensor (pageable, as the reference returns) through the pinned ring (vstab_download).
+        mask=True (a float32 padding mask): vstab_download_mask_coded -- a mask of zeros and ones crosses as bytes and is
+        expanded by the host threads, any other mask takes the plain path.  `last_download_coded` tells which."""
         torch = self.torch
         src = device_tensor.contiguous()
         dst = torch.empty(src.shape, dtype=src.dtype)
         self.use_torch_stream()
-        _check(self.lib.vstab_download(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel() * src.element_size()), "vstab_download")
+        if mask and src.dtype == torch.float32 and _coded_transfers():
+            coded = C.c_int(0)
+            _check(self.lib.vstab_download_mask_coded(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel(), C.byref(coded)), "vstab_download_mask_coded")
+            self.last_download_coded = bool(coded.value)
+        else:
+            _check(self.lib.vstab_download(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel() * src.element_size()), "vstab_download")
+            self.last_download_coded = False
         return dst
 
     # ------------------------------------------------------------------ warp

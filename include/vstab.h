@@ -83,6 +83,17 @@ int vstab_kernel_ms_stats(vstab_ctx* ctx, const char* kind, double* total_ms, in
  * enqueued on the context's stream and returns when host_dst is complete. */
 int vstab_upload(vstab_ctx* ctx, const void* host_src, void* dev_dst, size_t bytes);
 int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_dst, size_t bytes);
+/* The same two transfers with fewer bytes on PCIe where the DATA allow it; the destination holds the source's bits either way.
+ * vstab_upload_f32_coded: `count` float32 values.  A ComfyUI IMAGE decoded from 8-bit video holds float32(k) / float32(255)
+ * and nothing else (what nodes/stabilizer_utils.py:122-126 itself produces for uint8 input): a chunk (2^25 values) whose values
+ * all have exactly the bits of such a quotient crosses as bytes and is expanded on the device by the same correctly rounded
+ * division; the first chunk with a value of any other kind, and everything behind it, crosses as float32.  *coded_chunks
+ * (may be NULL) = chunks that crossed as bytes.  dev_dst 16-byte aligned.
+ * vstab_download_mask_coded: `count` float32 mask values (nodes/stabilizer_utils.py:1055-1077).  If every value is 0.0f or
+ * 1.0f (the Flow node's mask, nodes/video_stabilizer_flow.py:583-586) they cross as bytes and the host threads expand them;
+ * otherwise (Motion Apply's soft mask under motion blur) this is vstab_download.  *coded (may be NULL) = 1 / 0. */
+int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks);
+int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded);
 
 /* ---- F13 / A3: per-frame warp with padding mask ---------------------------
  * Replaces the loop at nodes/video_stabilizer_flow.py:560-588 and

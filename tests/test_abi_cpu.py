@@ -535,3 +535,41 @@ def test_shipped_library_has_no_fault_injectors(pkg):
     out = subprocess.run([sys.executable, "-c", f"import ctypes; print(ctypes.CDLL({str(hooks)!r}).vstab_test_hooks())"],
                          capture_output=True, text=True, timeout=120)
     assert out.stdout.strip() == "1", out.stderr[-2000:]
+
+
+def test_coded_transfer_host_loops(pkg):
+    """The host halves of the coded node-boundary transfers (csrc/vstab_codec.cpp, called by vstab_upload_f32_coded /
+    vstab_download_mask_coded): a run of values is accepted for the byte form only if EVERY value has exactly the bits of
+    float32(k) / float32(255) -- what nodes/stabilizer_utils.py:122-126 makes of an 8-bit frame -- and the bytes are those k;
+    one value of any other kind anywhere in the run (vector body or scalar tail) rejects it."""
+    import ctypes
+
+    from vstab_amd import native
+
+    lib = native.load_library()
+    enc, exp = lib.vstab_host_encode_q8, lib.vstab_host_expand_mask
+    enc.restype, enc.argtypes = ctypes.c_bool, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    exp.restype, exp.argtypes = None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 31, 32, 33, 1000, 4099):
+        k = rng.integers(0, 256, n).astype(np.uint8)
+        v = k.astype(np.float32) / np.float32(255.0)
+        out = np.full(n, 77, np.uint8)
+        assert enc(v.ctypes.data, out.ctypes.data, n) and np.array_equal(out, k)
+        for special in (0.5, np.nan, -0.0, np.nextafter(np.float32(1.0), np.float32(2.0)), -1e-9, 255.0, np.inf, -np.inf,
+                        np.nextafter(np.float32(3.0) / np.float32(255.0), np.float32(0.0)), 1e-40, 3e9, -3e9):
+            for pos in {0, n // 2, n - 1}:
+                w = v.copy()
+                w[pos] = special
+                assert not enc(w.ctypes.data, out.ctypes.data, n), (n, special, pos)
+        back = np.empty(n, np.float32)
+        exp(k.ctypes.data, back.ctypes.data, n)
+        assert np.array_equal(back.view(np.uint32), np.where(k != 0, np.float32(1.0), np.float32(0.0)).view(np.uint32))
+    # every quotient, and both of its float32 neighbours (never a quotient themselves)
+    q = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    out = np.empty(256, np.uint8)
+    assert enc(q.ctypes.data, out.ctypes.data, 256) and np.array_equal(out, np.arange(256, dtype=np.uint8))
+    for nb in (np.nextafter(q[1:], np.float32(0.0)), np.nextafter(q[1:], np.float32(2.0))):
+        for i in range(255):
+            one = nb[i:i + 1].copy()
+            assert not enc(one.ctypes.data, out.ctypes.data, 1)
