@@ -309,17 +309,15 @@ unsigned grid_for(size_t items16)
 
 }  // namespace
 
-extern "C" int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks)
+// `count` values to dev_dst as float32(k) / 255: from float32 values that are such quotients (SRC_FLOAT: checked value by
+// value, stops at the first chunk that holds anything else) or from the bytes k themselves.  *chunks_done = leading chunks
+// that crossed as bytes.
+template <bool SRC_FLOAT>
+static int upload_as_bytes(vstab_ctx* ctx, const void* host_src, float* dev_dst, size_t count, size_t* chunks_done, const char* who)
 {
-    VSTAB_REQUIRE(ctx != nullptr, "vstab_upload_f32_coded: ctx is NULL");
-    VSTAB_REQUIRE(count == 0 || (host_src && dev_dst), "vstab_upload_f32_coded: NULL pointer argument");
-    if (coded_chunks) *coded_chunks = 0;
-    if (count == 0) return 0;
-    VSTAB_REQUIRE((reinterpret_cast<uintptr_t>(dev_dst) & 15) == 0, "vstab_upload_f32_coded: dev_dst must be 16-byte aligned");
-    VSTAB_HIP(hipSetDevice(ctx->device));
     Ring r;
     if (ring_get(ctx, r)) return 1;
-    if (ctx->d_xfer.reserve(QCHUNK * SLOTS)) return 1;        // the coded chunks' landing slots on the device
+    if (ctx->d_xfer.reserve(QCHUNK * SLOTS)) return 1;        // the byte chunks' landing slots on the device
     unsigned char* dslot = static_cast<unsigned char*>(ctx->d_xfer.ptr);
     if (!ctx->ev_xfer_sync) VSTAB_HIP(hipEventCreateWithFlags(&ctx->ev_xfer_sync, hipEventDisableTiming));
     VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->stream));                 // as vstab_upload: dev_dst may still be in use on the stream
@@ -338,12 +336,19 @@ extern "C" int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, flo
                 team.sync();
                 size_t lo, hi;
                 team.share(me, len, lo, hi);
-                if (hi > lo && !vstab_host_encode_q8(host_src + off + lo, reinterpret_cast<unsigned char*>(r.slot[s]) + lo, hi - lo)) chunk_bad[c & 1] = 1;
+                unsigned char* slot = reinterpret_cast<unsigned char*>(r.slot[s]);
+                if (hi > lo) {
+                    if (SRC_FLOAT) {
+                        if (!vstab_host_encode_q8(static_cast<const float*>(host_src) + off + lo, slot + lo, hi - lo)) chunk_bad[c & 1] = 1;
+                    } else {
+                        memcpy(slot + lo, static_cast<const unsigned char*>(host_src) + off + lo, hi - lo);
+                    }
+                }
                 team.sync();
                 if (chunk_bad[c & 1] != 0 || team.failed) return;   // every member takes the same decision from the same flags
                 if (me == 0) {
                     chunk_bad[(c + 1) & 1] = 0;               // nobody touches it before the next chunk's first barrier
-                    hipError_t e = hipMemcpyAsync(dslot + (size_t)s * QCHUNK, r.slot[s], len, hipMemcpyHostToDevice, ctx->xfer_stream);
+                    hipError_t e = hipMemcpyAsync(dslot + (size_t)s * QCHUNK, slot, len, hipMemcpyHostToDevice, ctx->xfer_stream);
                     if (e == hipSuccess) e = hipEventRecord(r.done[s], ctx->xfer_stream);
                     if (e == hipSuccess) {
                         // (the next copy into this device slot is queued behind the kernel on the same stream)
@@ -356,17 +361,42 @@ extern "C" int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, flo
                 }
             }
         };
-        team.run(count * sizeof(float) < (size_t(4) << 20) ? 1 : xfer_threads(), body);
-        VSTAB_REQUIRE(!team.failed, "vstab_upload_f32_coded: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+        team.run(count < (size_t(1) << 20) ? 1 : xfer_threads(), body);
+        VSTAB_REQUIRE(!team.failed, "%s: a HIP call failed: %s", who, hipGetErrorString(hipGetLastError()));
     }
     // the last chunk's expansion is the last thing on the copy stream: later work on the context's stream waits for it
     VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->xfer_stream));
     VSTAB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_xfer_sync, 0));
+    *chunks_done = coded;
+    return 0;
+}
+
+extern "C" int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_upload_f32_coded: ctx is NULL");
+    VSTAB_REQUIRE(count == 0 || (host_src && dev_dst), "vstab_upload_f32_coded: NULL pointer argument");
+    if (coded_chunks) *coded_chunks = 0;
+    if (count == 0) return 0;
+    VSTAB_REQUIRE((reinterpret_cast<uintptr_t>(dev_dst) & 15) == 0, "vstab_upload_f32_coded: dev_dst must be 16-byte aligned");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    size_t coded = 0;
+    if (int rc = upload_as_bytes<true>(ctx, host_src, dev_dst, count, &coded, "vstab_upload_f32_coded")) return rc;
     if (coded_chunks) *coded_chunks = coded;
     // a chunk with a value of another kind: it and everything behind it cross as float32 (the ring's slots are guarded by their events)
     const size_t done = coded * QCHUNK;
     if (done < count) return vstab_upload(ctx, host_src + done, dev_dst + done, (count - done) * sizeof(float));
     return 0;
+}
+
+extern "C" int vstab_upload_u8_as_f32(vstab_ctx* ctx, const unsigned char* host_src, float* dev_dst, size_t count)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_upload_u8_as_f32: ctx is NULL");
+    VSTAB_REQUIRE(count == 0 || (host_src && dev_dst), "vstab_upload_u8_as_f32: NULL pointer argument");
+    if (count == 0) return 0;
+    VSTAB_REQUIRE((reinterpret_cast<uintptr_t>(dev_dst) & 15) == 0, "vstab_upload_u8_as_f32: dev_dst must be 16-byte aligned");
+    VSTAB_HIP(hipSetDevice(ctx->device));
+    size_t done = 0;
+    return upload_as_bytes<false>(ctx, host_src, dev_dst, count, &done, "vstab_upload_u8_as_f32");
 }
 
 extern "C" int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded)

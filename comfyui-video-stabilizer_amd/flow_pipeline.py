@@ -206,6 +206,10 @@ def _host_frames(context: hm.VideoContext) -> np.ndarray:
     if context.batch is not None:
         hm.resolve_value_range(context)
         return context.batch.detach().cpu().numpy()
+    if context.batch_u8 is not None:
+        arr = context.batch_u8.numpy().astype(np.float32)
+        arr /= 255.0
+        return arr
     return np.stack([hm._ensure_rgb(f) for f in context.frames], axis=0)
 
 

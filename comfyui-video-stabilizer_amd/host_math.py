@@ -53,10 +53,16 @@ class VideoContext:
     # `batch`: the GPU pipelines get the per-frame maxima from their first pass over the pixels (the gray kernel, or
     # vstab_frame_range) instead of reading the clip once more on the host, and call resolve_value_range().
     range_pending: bool = False
+    # a uint8 [N,H,W,3] CPU tensor whose float32 form (stabilizer_utils.py:122-126: astype(float32) / 255) has not been made
+    # yet: the GPU pipelines get it from the library (the bytes cross PCIe, the division runs on the device), host-only
+    # paths from NumPy (_host_frames)
+    batch_u8: Any = field(default=None, repr=False)
 
     def device_batch(self, ctx):
         """[N,H,W,3] f32 tensor on ctx.device (uploaded once, cached)."""
         t = self.batch
+        if t is None and self.batch_u8 is not None:
+            t = ctx.upload_u8_as_f32(self.batch_u8)
         if t is None:
             t = torch.from_numpy(np.ascontiguousarray(np.stack(self.frames, axis=0), dtype=np.float32))
         if t.device != ctx.device:
@@ -135,6 +141,18 @@ def _fast_batch(value: Any):
         return None
     n, h, w, _ = value.shape
     if h <= 4:  # tiny heights can trip the reference's per-frame channel-first sniff: take the slow path
+        return None
+    return value.detach().contiguous()
+
+
+def _fast_batch_u8(value: Any):
+    """A uint8 [N,H,W,3] CPU tensor on a box with a GPU: kept as bytes until a pipeline asks for the device batch
+    (VideoContext.batch_u8); everything else takes the per-frame path."""
+    if torch is None or not isinstance(value, torch.Tensor):
+        return None
+    if value.ndim != 4 or value.dtype != torch.uint8 or value.shape[-1] != 3 or value.shape[0] == 0 or value.device.type != "cpu":
+        return None
+    if value.shape[1] <= 4 or not torch.cuda.is_available():
         return None
     return value.detach().contiguous()
 
@@ -233,6 +251,12 @@ def _normalize_video_input(value: Any) -> VideoContext:
         views = [host[i].numpy() if host is not None else None for i in range(n)]
         adapter = FrameAdapter(np.dtype(np.float32), False, "0_1", "torch", False)
         return VideoContext(views, adapter, int(w), int(h), 3, fps, kind, tmeta, batch=batch, range_pending=True)
+
+    batch_u8 = _fast_batch_u8(seq)
+    if batch_u8 is not None:
+        n, h, w, _ = batch_u8.shape
+        adapter = FrameAdapter(np.dtype(np.uint8), False, "0_255", "torch", False)
+        return VideoContext([None] * n, adapter, int(w), int(h), 3, fps, kind, tmeta, batch_u8=batch_u8)
 
     frames: List[np.ndarray] = []
     first: Optional[FrameAdapter] = None

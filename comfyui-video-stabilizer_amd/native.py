@@ -109,6 +109,7 @@ _SIGNATURES = {
     "vstab_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_upload_f32_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vstab_upload_u8_as_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_download_mask_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "vstab_warp_batch": (
         C.c_int,
@@ -395,6 +396,18 @@ class Context:
         else:
             _check(self.lib.vstab_upload(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel() * src.element_size()), "vstab_upload")
             self.last_upload_coded = (0, -(-src.numel() // (32 << 20)))
+        return dst
+
+    def upload_u8_as_f32(self, host_tensor):
+        """uint8 CPU tensor -> new float32 device tensor holding float32(k) / 255 (stabilizer_utils.py:122-126): the bytes cross
+        PCIe, the division runs on the device (vstab_upload_u8_as_f32)."""
+        torch = self.torch
+        src = host_tensor.contiguous()
+        if src.dtype != torch.uint8 or src.device.type != "cpu":
+            raise VstabError("upload_u8_as_f32: a uint8 CPU tensor is required")
+        dst = torch.empty(src.shape, dtype=torch.float32, device=self.device)
+        self.use_torch_stream()
+        _check(self.lib.vstab_upload_u8_as_f32(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel()), "vstab_upload_u8_as_f32")
         return dst
 
     def download(self, device_tensor, mask=False):

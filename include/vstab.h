@@ -91,8 +91,12 @@ int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_dst, size_t b
  * (may be NULL) = chunks that crossed as bytes.  dev_dst 16-byte aligned.
  * vstab_download_mask_coded: `count` float32 mask values (nodes/stabilizer_utils.py:1055-1077).  If every value is 0.0f or
  * 1.0f (the Flow node's mask, nodes/video_stabilizer_flow.py:583-586) they cross as bytes and the host threads expand them;
- * otherwise (Motion Apply's soft mask under motion blur) this is vstab_download.  *coded (may be NULL) = 1 / 0. */
+ * otherwise (Motion Apply's soft mask under motion blur) this is vstab_download.  *coded (may be NULL) = 1 / 0.
+ * vstab_upload_u8_as_f32: `count` uint8 values k arrive on the device as float32(k) / float32(255) -- _to_numpy_frame's uint8
+ * branch, `arr.astype(np.float32); arr /= 255.0` (nodes/stabilizer_utils.py:122-126), without the host ever holding the floats.
+ */
 int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks);
+int vstab_upload_u8_as_f32(vstab_ctx* ctx, const unsigned char* host_src, float* dev_dst, size_t count);
 int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded);
 
 /* ---- F13 / A3: per-frame warp with padding mask ---------------------------

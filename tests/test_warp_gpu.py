@@ -185,7 +185,7 @@ def test_every_entry_point_rejects_empty_arguments(pkg):
     lib = c.lib
     # calls that legitimately succeed with these arguments (zero-byte transfers are no-ops)
     benign = {"vstab_destroy", "vstab_create", "vstab_set_stream", "vstab_synchronize", "vstab_set_timing", "vstab_dis_set_clip_start",
-              "vstab_upload", "vstab_download", "vstab_upload_f32_coded", "vstab_download_mask_coded"}
+              "vstab_upload", "vstab_download", "vstab_upload_f32_coded", "vstab_upload_u8_as_f32", "vstab_download_mask_coded"}
     checked = 0
     for name, params in header_prototypes():
         if not params or not params[0].startswith("vstab_ctx*") or name in benign:

@@ -117,3 +117,48 @@ def test_flow_node_outputs_do_not_depend_on_the_coded_transfers(pkg, ctx, monkey
     ref = nodes.VideoStabilizerFlow.execute(torch.from_numpy(frames), *args)
     assert ctx.last_upload_coded[0] == 0 and ctx.last_download_coded is False
     assert torch.equal(bits(out[0]), bits(ref[0])) and torch.equal(bits(out[1]), bits(ref[1])) and out[2] == ref[2]
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, (1 << 20) + 3, QCHUNK + 5, QCHUNK * 5 - 8])
+def test_uint8_upload_is_numpys_division(ctx, n):
+    """vstab_upload_u8_as_f32: the device tensor has the bits of `arr.astype(np.float32) / 255.0` (stabilizer_utils.py:122-126)."""
+    import torch
+
+    k = torch.randint(0, 256, (n,), generator=torch.Generator().manual_seed(n % 983), dtype=torch.uint8)
+    ref = k.numpy().astype(np.float32)
+    ref /= 255.0
+    dev = ctx.upload_u8_as_f32(k)
+    assert dev.dtype == torch.float32 and torch.equal(bits(dev.cpu()), bits(torch.from_numpy(ref)))
+
+
+def test_uint8_clips_through_the_nodes_equal_their_float_form(pkg, ctx):
+    """F0's uint8 branch at the node boundary: a uint8 [N,H,W,3] CPU tensor gives what the same clip as float32(k) / 255 gives --
+    frames, masks, meta -- through the Flow node (normal path, single frame, crop bypass) and Motion Apply; the adapter records
+    the uint8 origin as the reference's does."""
+    import torch
+
+    from tests.util import synth_frames
+    from vstab_amd import host_math as hm
+    from vstab_amd import nodes
+
+    u8 = np.clip(np.round(synth_frames(6, 270, 480, seed=9) * 255.0), 0, 255).astype(np.uint8)
+    f32 = u8.astype(np.float32)
+    f32 /= 255.0
+    c = hm._normalize_video_input(torch.from_numpy(u8))
+    assert c.adapter.dtype == np.uint8 and c.adapter.value_range == "0_255" and not c.range_pending and (c.width, c.height) == (480, 270)
+    slow = hm._normalize_video_input([torch.from_numpy(f) for f in u8])          # the per-frame path of the reference
+    assert (slow.adapter.dtype, slow.adapter.value_range, slow.adapter.origin) == (c.adapter.dtype, c.adapter.value_range, c.adapter.origin)
+    assert torch.equal(bits(c.device_batch(ctx).cpu()), bits(torch.from_numpy(f32)))
+    for args in [(16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F"),
+                 (16.0, "crop", "similarity", False, 0.7, 0.5, 1.0, "#102030"),              # crop bypass: the original frames come back
+                 (16.0, "expand", "translation", False, 0.7, 0.5, 0.6, "#7F7F7F")]:
+        a = nodes.VideoStabilizerFlow.execute(torch.from_numpy(u8), *args)
+        b = nodes.VideoStabilizerFlow.execute(torch.from_numpy(f32), *args)
+        assert torch.equal(bits(a[0]), bits(b[0])) and torch.equal(bits(a[1]), bits(b[1])) and a[2] == b[2], args
+    a = nodes.VideoStabilizerFlow.execute(torch.from_numpy(u8[:1]), 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")
+    assert torch.equal(bits(a[0]), bits(torch.from_numpy(f32[:1])))                 # single-frame passthrough
+    meta = nodes.VideoStabilizerFlow.execute(torch.from_numpy(f32), 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")[2]
+    for blur, quality in ((0.0, "Standard"), (0.5, "High")):
+        a = nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(u8), meta, "crop_and_pad", "bilinear", "#7F7F7F", blur, quality)
+        b = nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(f32), meta, "crop_and_pad", "bilinear", "#7F7F7F", blur, quality)
+        assert torch.equal(bits(a[0]), bits(b[0])) and torch.equal(bits(a[1]), bits(b[1]))
