@@ -425,7 +425,7 @@ def launch_children(args, argv) -> int:
     return proc.returncode
 
 
-def measure_host_roundtrip(nodes, frames_host, repeats: int = 2) -> dict:
+def measure_host_roundtrip(nodes, frames_host, repeats: int = 3) -> dict:
     """The node exactly as ComfyUI calls it (stabilizer_utils.py:200-221: CPU tensors out)."""
     import torch
 
