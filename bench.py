@@ -569,6 +569,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
     agree(alloc_ok, "allocating the clip")
     stats: dict = {}
     lap = {"flow": 0.0, "apply": 0.0}
+    plan_seen: list = []   # the Flow half's device-plan verdict per step ({"used", "mismatched_frames"}; sharded: in stats)
 
     def step():
         t0 = time.perf_counter()
@@ -579,6 +580,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
         else:
             res = fp._stabilize_frames(hm._normalize_video_input(frames), *C5_FLOW_ARGS, ctx=ctx, keep_on_device=True)
             meta = res.meta
+            plan_seen.append(res.device_plan)
             del res
             t1 = time.perf_counter()
             r = ap.apply_motion(hm._normalize_video_input(frames), meta, (127, 127, 127), ctx=ctx, keep_on_device=True, **C5_APPLY)
@@ -607,6 +609,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
     fence()
     ctx.set_timing(True)
     stats.clear()
+    plan_seen.clear()
     lap["flow"] = lap["apply"] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -630,6 +633,9 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
            "frames_per_gpu": n_local, "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "scaling": "strong", "out_shape_rank0": shape, "motion_blur_samples": ameta["motion_apply"]["motion_blur_samples"],
            "rank0_stage_ms": stage_ms,
+           "rank0_device_plan": ({"used": all(bool(v and v.get("used")) for v in plan_seen),
+                                  "mismatched_frames_max_per_step": max(int((v or {}).get("mismatched_frames", 0)) for v in plan_seen)}
+                                 if plan_seen else stats.get("device_plan")),
            "rank0_host_ms": {"flow_half": round(lap["flow"] / steps * 1e3, 3), "apply_half_launch": round(lap["apply"] / steps * 1e3, 3),
                              **{k: round(v / steps, 3) for k, v in stats.items() if isinstance(v, (int, float))}},
            "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo for the Flow half, RCCL all-gather "

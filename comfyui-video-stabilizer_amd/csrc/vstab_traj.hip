@@ -17,8 +17,9 @@
 // entry with probability ~1e-8.  So the host still computes the plan exactly (while the warp runs -- it needs the fit
 // records for the meta anyway) and compares its float32 final matrices with the device's, bit for bit; a frame whose
 // matrices differ is warped again with the host's matrix (flow_pipeline.py).  The outputs are therefore always those of
-// the host plan; the device plan only removes the wait.  Models with a perspective row are not speculated on: their
-// final = T @ M has two-term sums whose float32 rounding depends on NumPy's BLAS (fused or not).
+// the host plan; the device plan only removes the wait.  A perspective plan has no libm call at all (its parameters are the
+// matrix entries), but its final = T @ M has sums of two inexact terms whose float32 rounding depends on how NumPy's matmul
+// forms them (fused or not): the kernel takes the unfused form, and the verification catches the rare frame where that matters.
 #include "vstab_internal.h"
 #include <cmath>
 #include <cstdlib>
@@ -35,7 +36,7 @@ struct PlanArgs {
     int segments;                  // 0: contiguous.  > 0: the all-gather's receive buffer as it is -- one block of seg_rows
     int seg_rows;                  //    records rows per rank, of which the first seg_start[r + 1] - seg_start[r] are valid
     int seg_start[PLAN_MAX_SEG + 1];
-    int pairs, mode;               // requested model: VSTAB_MODE_TRANSLATION | VSTAB_MODE_SIMILARITY
+    int pairs, mode;               // requested model: VSTAB_MODE_TRANSLATION | VSTAB_MODE_SIMILARITY | VSTAB_MODE_PERSPECTIVE
     int rescale;                   // 1: F = f32(fl(up_i * M_ij) * down_j), 0: F = M
     double up[3], down[3];
     int window, do_smooth, camera_lock;
@@ -91,7 +92,7 @@ __device__ void reduce_region(double v[4], double* s_red /*[4][PLAN_T / 64]*/, b
 __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
 {
     extern __shared__ double s_path[];
-    const int p = a.mode == VSTAB_MODE_SIMILARITY ? 4 : 2;
+    const int p = a.mode == VSTAB_MODE_PERSPECTIVE ? 8 : (a.mode == VSTAB_MODE_SIMILARITY ? 4 : 2);
     for (int i = threadIdx.x; i < a.zero_n; i += PLAN_T) a.zero[i] = 0u;   // (a fill kernel of its own cost the stream ~17 us before the warp)
     const int frames = a.pairs + 1, total = frames * p;
     double* s_red = s_path + total;                                  // [4][PLAN_T / 64]
@@ -106,6 +107,30 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     __shared__ int s_first;
     if (threadIdx.x == 0) s_first = a.pairs;
     __syncthreads();
+    if (a.mode == VSTAB_MODE_PERSPECTIVE) {
+        // three models: which fits of each pair are usable goes to LDS in parallel (one byte per pair), then one lane
+        // replays the walk as written -- the active mode keeps winning until its fit is rejected, then the best usable
+        // model below it is used and becomes the active one (none: identity, active = translation) -- ~50 cycles a pair
+        for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
+            const vstab_fit_record* r = pair_records(a, i);
+            int bits = 0;
+            for (int m = 0; m < 3; m++) bits |= (r[m].computed != 0 && r[m].accepted != 0) ? (1 << m) : 0;
+            s_mode[i] = (signed char)bits;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int active = VSTAB_MODE_PERSPECTIVE;
+            for (int i = 0; i < a.pairs; i++) {
+                const int bits = s_mode[i];
+                int pick = -1;
+                for (int m = active; m >= 0; m--)
+                    if (bits & (1 << m)) { pick = m; break; }
+                s_mode[i] = (signed char)pick;
+                active = pick >= 0 ? pick : VSTAB_MODE_TRANSLATION;
+            }
+        }
+        __syncthreads();
+    } else {
     if (a.mode == VSTAB_MODE_SIMILARITY) {
         int mine = a.pairs;
         for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
@@ -126,6 +151,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
         s_mode[i] = (signed char)pick;
     }
     __syncthreads();
+    }
     // ---- rescale to full resolution + parameter deltas of the REQUESTED model (flow.py:340-346), into the path array
     for (int t = threadIdx.x; t < p; t += PLAN_T) s_path[t] = 0.0;
     for (int i = threadIdx.x; i < a.pairs; i += PLAN_T) {
@@ -146,6 +172,12 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
                 }
             }
         double* P = s_path + (size_t)(i + 1) * p;
+        if (a.mode == VSTAB_MODE_PERSPECTIVE) {   // the matrix entries themselves, identity removed in float32 (vstab_transitions_to_params)
+            const float d0 = F[0] - 1.0f, d4 = F[4] - 1.0f;
+            P[0] = (double)d0; P[1] = (double)F[1]; P[2] = (double)F[2]; P[3] = (double)F[3];
+            P[4] = (double)d4; P[5] = (double)F[5]; P[6] = (double)F[6]; P[7] = (double)F[7];
+            continue;
+        }
         P[0] = (double)F[2]; P[1] = (double)F[5];
         if (a.mode == VSTAB_MODE_SIMILARITY) {
             const float fa = F[0], fc = F[3];
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     double reg[4] = {uni ? INFINITY : -INFINITY, uni ? INFINITY : -INFINITY, uni ? -INFINITY : INFINITY, uni ? -INFINITY : INFINITY};
     float A[9];
     for (int i = threadIdx.x; i < frames; i += PLAN_T) {
-        double diff[4];
+        double diff[8];
         for (int c = 0; c < p; c++) {
             const double cur = s_path[i * p + c];
             double sm = cur;
@@ -207,7 +239,12 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
             a.target[(size_t)i * p + c] = tgt;
             diff[c] = tgt - cur;
         }
-        if (a.mode == VSTAB_MODE_SIMILARITY) {
+        A[6] = 0.f; A[7] = 0.f; A[8] = 1.f;
+        if (a.mode == VSTAB_MODE_PERSPECTIVE) {
+            A[0] = (float)(diff[0] + 1.0); A[1] = (float)diff[1]; A[2] = (float)diff[2];
+            A[3] = (float)diff[3]; A[4] = (float)(diff[4] + 1.0); A[5] = (float)diff[5];
+            A[6] = (float)diff[6]; A[7] = (float)diff[7];
+        } else if (a.mode == VSTAB_MODE_SIMILARITY) {
             const double s = exp(diff[3]), ct = cos(diff[2]), st = sin(diff[2]);
             const double sc = s * ct, ss = s * st;
             A[0] = (float)sc; A[1] = (float)(-ss); A[2] = (float)diff[0];
@@ -216,7 +253,6 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
             A[0] = 1.f; A[1] = 0.f; A[2] = (float)diff[0];
             A[3] = 0.f; A[4] = 1.f; A[5] = (float)diff[1];
         }
-        A[6] = 0.f; A[7] = 0.f; A[8] = 1.f;
         for (int k = 0; k < 9; k++) a.final32[(size_t)i * 9 + k] = A[k];   // the apply matrix, recentred below
         const double cx[4] = {0.0, a.width, 0.0, a.width}, cy[4] = {0.0, 0.0, a.height, a.height};
         double xs[4], ys[4];
@@ -245,7 +281,8 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(PlanArgs a)
     if (threadIdx.x == 0) for (int k = 0; k < 4; k++) a.region[k] = reg[k];
     const float off_x = uni ? (float)(-reg[0]) : (float)(a.width * 0.5 - (reg[0] + reg[2]) * 0.5);
     const float off_y = uni ? (float)(-reg[1]) : (float)(a.height * 0.5 - (reg[1] + reg[3]) * 0.5);
-    // ---- final = T @ A in float32 (A is affine: every sum has one inexact term), inverted into the warp's table
+    // ---- final = T @ A in float32 (affine A: every sum has one inexact term; perspective A: off * A[6 + c] is rounded before it
+    //      is added, the unfused form), inverted into the warp's table
     for (int i = threadIdx.x; i < frames; i += PLAN_T) {
         float* Fm = a.final32 + (size_t)i * 9;
         float R[9];
@@ -338,12 +375,12 @@ extern "C" int vstab_flow_plan_device(vstab_ctx* ctx, const vstab_fit_record* d_
     if (ctx) { ctx->plan_zero_ptr = nullptr; ctx->plan_zero_n = 0; ctx->plan_zeroed_ptr = nullptr; }
     VSTAB_REQUIRE(ctx != nullptr && d_records != nullptr, "vstab_flow_plan_device: NULL argument");
     VSTAB_REQUIRE(pairs >= 1, "vstab_flow_plan_device: needs at least one transition");
-    VSTAB_REQUIRE(requested_mode == VSTAB_MODE_TRANSLATION || requested_mode == VSTAB_MODE_SIMILARITY,
-                  "vstab_flow_plan_device: only translation / similarity plans are formed on the device (mode %d)", requested_mode);
+    VSTAB_REQUIRE(requested_mode == VSTAB_MODE_TRANSLATION || requested_mode == VSTAB_MODE_SIMILARITY || requested_mode == VSTAB_MODE_PERSPECTIVE,
+                  "vstab_flow_plan_device: unknown model %d", requested_mode);
     VSTAB_REQUIRE((up == nullptr) == (down == nullptr), "vstab_flow_plan_device: up and down come together");
     VSTAB_REQUIRE(width > 0 && height > 0, "vstab_flow_plan_device: non-positive frame size");
     VSTAB_REQUIRE(framing == 0 || framing == 1, "vstab_flow_plan_device: framing %d (0 = crop_and_pad, 1 = expand; crop is the host's keep_fov solver)", framing);
-    const int p = requested_mode == VSTAB_MODE_SIMILARITY ? 4 : 2, frames = pairs + 1;
+    const int p = requested_mode == VSTAB_MODE_PERSPECTIVE ? 8 : (requested_mode == VSTAB_MODE_SIMILARITY ? 4 : 2), frames = pairs + 1;
     const size_t lds = sizeof(double) * ((size_t)frames * p + 4 * (PLAN_T / 64)) + (((size_t)pairs + 15) & ~size_t(15));
     VSTAB_REQUIRE(lds <= PLAN_LDS_MAX, "vstab_flow_plan_device: a clip of %d frames does not fit the plan kernel's LDS", frames);
     VSTAB_HIP(hipSetDevice(ctx->device));

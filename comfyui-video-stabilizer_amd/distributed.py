@@ -405,7 +405,7 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
             ctx.flow_plan_device(flat.data_ptr(), total_frames - 1, transform_mode, size, working_size, smooth, fps_effective, strength,
                                  bool(camera_lock), seg_pairs=per_rank, seg_rows=rows + 1, warp_frames=n_local, framing=framing_mode)
             if framing_mode == "expand":   # the canvas comes from the (replicated) plan kernel's region, see flow_pipeline
-                out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[3])
+                out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, _fp.PLAN_PARAMS[transform_mode])[3])
                 if out_size is None:
                     raise native.VstabError("the device plan's expand region is not finite")
                 dst = torch.empty((0, out_size[1], out_size[0], 3), dtype=torch.float32, device=own.device)
@@ -430,7 +430,7 @@ def _stabilize_sharded_device_plan(ctx, local_frames, total_frames, start, n_loc
             plan = plan_stabilization(ctx, records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
                                       keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
             t0 = _lap(stats, "plan", t0)
-            final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
+            final_dev = ctx.flow_plan_result(total_frames, _fp.PLAN_PARAMS[transform_mode])[0]
             if tuple(plan.output_size) != tuple(out_size):
                 # expand: the host's canvas differs from the device's by a pixel (an extent within one ulp of an integer) -- on every
                 # rank alike, the plan being replicated: this rank's frames are warped again onto the host plan's canvas

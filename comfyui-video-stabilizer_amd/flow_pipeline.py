@@ -454,7 +454,8 @@ def finish_meta(plan: FlowPlan, pad_counts) -> Dict[str, Any]:
 # device's bit for bit: a frame whose matrix differs (the device's atan2 / log / exp / cos / sin may differ from glibc's in
 # the last bit of a double, which survives the float32 cast about once in 1e8 entries) is warped again with the host's.
 # What is returned is therefore always the host plan's result.  VSTAB_DEVICE_PLAN=0 switches the speculation off (A/B).
-_DEVICE_PLAN_MAX_FRAMES = 4096          # plan_kernel keeps the path [frames, 4] fp64 in LDS
+_DEVICE_PLAN_MAX_FRAMES = 4096          # plan_kernel keeps the path [frames, 4] fp64 in LDS (perspective: [frames, 8], half as many)
+PLAN_PARAMS = {"translation": 2, "similarity": 4, "perspective": 8}   # parameters per frame of a model's path
 _DEVICE_PLAN_MAX_SEGMENTS = 64          # plan_kernel's segment table (PLAN_MAX_SEG in csrc/vstab_traj.hip): ranks of a sharded run
 
 
@@ -464,8 +465,9 @@ def device_plan_applies(estimator: str, framing_mode: str, transform_mode: str, 
     What a call did is reported in its result (`StabilizationResult.device_plan`, `stats["device_plan"]` of a sharded call):
     {"used": bool, "mismatched_frames": int} -- there is no module-level record."""
     return (os.environ.get("VSTAB_DEVICE_PLAN", "1") not in ("0", "false", "False") and estimator == "flow"
-            and framing_mode in ("crop_and_pad", "expand") and transform_mode in ("translation", "similarity")
-            and 2 <= total_frames <= _DEVICE_PLAN_MAX_FRAMES and 1 <= segments <= _DEVICE_PLAN_MAX_SEGMENTS)
+            and framing_mode in ("crop_and_pad", "expand") and transform_mode in PLAN_PARAMS
+            and 2 <= total_frames <= (_DEVICE_PLAN_MAX_FRAMES * 4) // max(PLAN_PARAMS[transform_mode], 4)
+            and 1 <= segments <= _DEVICE_PLAN_MAX_SEGMENTS)
 
 
 def _counts_to_host(counts, mirrored: bool = True) -> np.ndarray:
@@ -509,7 +511,7 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
     if framing_mode == "expand":
         # the canvas has to exist before the warp is queued: wait for the plan kernel's region (the plan's download, ~30 us
         # behind the fit kernel on the side stream -- not for the host's own plan, which runs under the warp as before)
-        out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[3])
+        out_size = ctx.expand_canvas(ctx.flow_plan_result(total_frames, PLAN_PARAMS[transform_mode])[3])
         if out_size is None:           # a non-finite region: nothing to speculate on
             ctx.sample_fit_batch_end(pairs)
             return None
@@ -523,7 +525,7 @@ def _stabilize_with_device_plan(ctx, context, device_frames, working_size, total
     plan = plan_stabilization(ctx, fit_records, size, total_frames, framing_mode, transform_mode, camera_lock, strength, smooth,
                               keep_fov, padding_rgb, fps_effective, fps_requested, estimator="flow")
     meta = prepare_meta(plan)                               # host JSON work overlaps the warp kernel
-    final_dev = ctx.flow_plan_result(total_frames, 4 if transform_mode == "similarity" else 2)[0]
+    final_dev = ctx.flow_plan_result(total_frames, PLAN_PARAMS[transform_mode])[0]
     if tuple(plan.output_size) != tuple(out_size):
         # expand: the host's canvas is a pixel wider / taller than the device's (an extent within one ulp of an integer): every
         # frame is warped again onto the host plan's canvas

@@ -310,7 +310,7 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
 
 /* ---- F6-F12 on the device, speculatively: fit records -> the warp's transform table, no host round trip ----
  * Replaces the stretch of nodes/video_stabilizer_flow.py:324-371 and :472-521 between the last model fit and the first
- * warp for framing_mode "crop_and_pad" with a translation / similarity model: sticky active_mode walk, rescale to full
+ * warp for framing_mode "crop_and_pad" / "expand" (any of the three models): sticky active_mode walk, rescale to full
  * resolution, parameter deltas of the requested model, path / _smooth_path / strength blend, _params_to_matrix,
  * _compute_bounding_boxes, the common region, the recentring shift and final = T @ M (float32), inverted as
  * cv2.warpPerspective inverts it.  One kernel on the context's stream.
@@ -319,8 +319,9 @@ int vstab_trajectory(vstab_ctx* ctx, const double* deltas, int n, int p, double 
  * The plan stays on the device for vstab_warp_batch_planned; its float32 final matrices, path, target and the common
  * region (x0, y0, x1, y1) are downloaded behind the kernel and handed out by vstab_flow_plan_result (waits for that
  * download only).  The device forms atan2 / log / exp / cos / sin with its own fp64 library, the reference with the host's
- * libm: the caller computes the plan on the host as well (vstab_transitions_to_params ... vstab_bounding_boxes), compares
- * the final matrices bit for bit and warps a frame again where they differ -- see flow_pipeline.py. */
+ * libm (a perspective plan has no such call, but its final = T @ M holds sums of two inexact float32 terms, which NumPy's matmul
+ * may or may not fuse): the caller computes the plan on the host as well (vstab_transitions_to_params ... vstab_bounding_boxes),
+ * compares the final matrices bit for bit and warps a frame again where they differ -- see flow_pipeline.py. */
 /* Optional, before vstab_flow_plan_device: the planned warp's padded-pixel count array (dev [n] u32); the plan kernel zeroes
  * it, and vstab_warp_batch_planned with the same pointer skips its own fill -- one launch less between plan and warp. */
 int vstab_flow_plan_zero_counts(vstab_ctx* ctx, uint32_t* pad_count, int n);

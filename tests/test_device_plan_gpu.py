@@ -34,23 +34,25 @@ def _fits(ctx, frames, mode):
     ("similarity", (640, 360), True, 0.5, 0.7, 16.0),         # camera_lock: target path 0
     ("translation", (960, 540), False, 0.0, 0.4, 16.0),       # smooth 0: the path is its own target
     ("translation", (1280, 720), False, 0.5, 0.7, 24.0),
+    ("perspective", (1920, 1080), False, 0.5, 0.7, 16.0),     # C3's Flow half: eight parameters, no libm; rescaled
+    ("perspective", (960, 540), True, 1.0, 1.0, 30.0),
 ])
 def test_device_plan_equals_host_plan(ctx, pkg, mode, size, camera_lock, smooth, strength, fps):
     from vstab_amd import flow_pipeline as fp
 
     w, h = size
     n = 24
-    frames = _clip(ctx, n, w, h, "similarity" if mode == "similarity" else "translation", amp=1.5)
+    frames = _clip(ctx, n, w, h, mode, amp=1.5)
     pairs, work = _fits(ctx, frames, mode)
     ctx.flow_plan_device(ctx.fit_records_device(), pairs, mode, size, work, smooth, fps, strength, camera_lock)
     table = ctx.sample_fit_batch_end(pairs)
-    final_dev, path_dev, target_dev, region = ctx.flow_plan_result(n, 4 if mode == "similarity" else 2)
+    final_dev, path_dev, target_dev, region = ctx.flow_plan_result(n, fp.PLAN_PARAMS[mode])
     plan = fp.plan_stabilization(ctx, table, size, n, "crop_and_pad", mode, camera_lock, strength, smooth, 0.6, (127, 127, 127),
                                  fps, fps)
     em = plan.estimated_motion
-    # translation parameters involve no libm at all: everything is bit-equal; similarity: the path may differ in the
-    # last unit of a double (device atan2 / log vs glibc), the float32 matrices must still agree
-    if mode == "translation":
+    # translation and perspective parameters involve no libm at all: everything is bit-equal; similarity: the path may differ
+    # in the last unit of a double (device atan2 / log vs glibc), the float32 matrices must still agree
+    if mode != "similarity":
         assert np.array_equal(path_dev, em["path"]) and np.array_equal(target_dev, em["target_path"])
     else:
         assert np.allclose(path_dev, em["path"], rtol=0, atol=4e-15 * max(1.0, np.abs(em["path"]).max()))
@@ -129,6 +131,20 @@ def test_flow_node_is_the_same_with_and_without_the_device_plan(ctx, pkg, monkey
     assert bool((a.frames == b.frames).all()) and bool((a.masks == b.masks).all())
 
 
+@pytest.mark.parametrize("framing", ["crop_and_pad", "expand"])
+def test_perspective_flow_is_the_same_with_and_without_the_device_plan(ctx, pkg, monkeypatch, framing):
+    """C3's Flow half on the device plan: same pixels, masks and meta as the host-plan flow.  Frames whose final = T @ M the
+    device rounded differently from NumPy's matmul (sums of two inexact terms) are warped again: a few at most."""
+    frames = _clip(ctx, 16, 1280, 720, "perspective", amp=1.5)
+    a, info_a = _run(ctx, frames, "perspective", monkeypatch, device_plan=False, framing=framing)
+    b, info_b = _run(ctx, frames, "perspective", monkeypatch, device_plan=True, framing=framing)
+    assert info_a == {"used": False, "mismatched_frames": 0} and info_b["used"] is True
+    assert info_b["mismatched_frames"] <= (2 if framing == "crop_and_pad" else 16)   # (expand: a canvas one pixel off re-warps all)
+    assert a.meta["transform_mode_applied"] == "perspective" and a.meta == b.meta
+    assert tuple(a.frames.shape) == tuple(b.frames.shape)
+    assert bool((a.frames == b.frames).all()) and bool((a.masks == b.masks).all())
+
+
 def test_a_wrong_device_plan_is_caught_and_the_frame_warped_again(pkg):
     """The TEST build's VSTAB_DEBUG_PLAN_PERTURB makes the device plan's matrix of one frame wrong by one ulp: the host's
     verification must catch it, warp that frame again, and return the host plan's result (the shipped library has no such
@@ -176,12 +192,77 @@ def test_plan_kernel_refuses_what_it_does_not_cover(ctx, pkg):
     from vstab_amd import native
 
     frames = _clip(ctx, 4, 640, 360, "similarity")
-    pairs, work = _fits(ctx, frames, "perspective")
-    with pytest.raises(native.VstabError, match="translation / similarity"):
-        ctx.flow_plan_device(ctx.fit_records_device(), pairs, "perspective", (640, 360), work, 0.5, 16.0, 0.7, False)
+    pairs, work = _fits(ctx, frames, "similarity")
+    with pytest.raises(native.VstabError, match="unknown model"):
+        native._check(ctx.lib.vstab_flow_plan_device(ctx.handle, ctx.fit_records_device(), pairs, 3, None, None, 0.5, 16.0, 0.7, 0, 640, 360,
+                                                     0, None, 0, 0), "vstab_flow_plan_device")
+    with pytest.raises(native.VstabError, match="framing"):
+        ctx.flow_plan_device(ctx.fit_records_device(), pairs, "similarity", (640, 360), work, 0.5, 16.0, 0.7, False, framing="crop")
     ctx.sample_fit_batch_end(pairs)
     with pytest.raises(native.VstabError, match="no fit"):
         ctx.sample_fit_batch_end(pairs)
+
+
+def test_sticky_mode_walk_of_a_perspective_plan(ctx, pkg):
+    """Three models: plan_kernel replays flow.py:324-339 pair by pair from the usable-fit flags (perspective until its fit is
+    rejected, then the best usable model below, which becomes the active one; none: identity, active = translation).  Tables
+    with every kind of step -- 2 -> 1 -> 0, 2 -> 0 directly, a pair with nothing usable, rejected fits of models that are no
+    longer (or not yet) active -- against flow_pipeline.select_transitions; no libm anywhere, so the paths are bit-equal."""
+    import torch
+
+    from vstab_amd import flow_pipeline as fp
+    from vstab_amd import native
+
+    rng = np.random.default_rng(5)
+    pairs = 41
+    for case in range(7):
+        table = np.zeros((pairs, 3), native.FIT_DTYPE)
+        for i in range(pairs):
+            for m in (0, 1, 2):
+                mat = np.eye(3, dtype=np.float32)
+                mat[0, 2], mat[1, 2] = rng.uniform(-3, 3, 2)
+                if m >= 1:
+                    c, s_ = np.cos(rng.uniform(-0.01, 0.01)), np.sin(rng.uniform(-0.01, 0.01))
+                    mat[0, 0] = mat[1, 1] = 1.002 * c
+                    mat[0, 1], mat[1, 0] = -1.002 * s_, 1.002 * s_
+                if m == 2:
+                    mat[2, 0], mat[2, 1] = rng.uniform(-2e-6, 2e-6, 2)
+                    mat[0, 0] += rng.uniform(-1e-3, 1e-3)
+                table[i, m]["matrix"] = mat.reshape(9)
+                table[i, m]["computed"] = table[i, m]["accepted"] = 1
+                table[i, m]["confidence"] = 0.9
+        if case == 1:
+            table[17, 2]["accepted"] = 0                                   # 2 -> 1 mid-clip
+            table[30, 1]["accepted"] = 0                                   # 1 -> 0 later
+        elif case == 2:
+            table[0, 2]["accepted"] = 0                                    # at the first pair, straight down to translation
+            table[0, 1]["computed"] = 0
+        elif case == 3:
+            table[pairs - 1, 2]["accepted"] = 0                            # at the last pair
+        elif case == 4:
+            table[8, 2]["accepted"] = table[8, 1]["accepted"] = table[8, 0]["accepted"] = 0   # nothing usable: identity, active = translation
+            table[20, 0]["computed"] = 0                                   # ... and another identity pair later
+        elif case == 5:
+            table[3, 1]["accepted"] = 0                                    # lower models rejected while perspective still wins: ignored
+            table[4, 0]["accepted"] = 0
+            table[25, 2]["computed"] = 0                                   # 2 -> 1
+            table[26, 2]["accepted"] = 1                                   # (a usable perspective fit after the step down is not taken up again)
+        elif case == 6:
+            table[10, 2]["accepted"] = 0
+            table[10, 1]["accepted"] = 0                                   # 2 -> 0 directly
+            table[11, 1]["accepted"] = 1
+        dev = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).to(ctx.device)
+        ctx.flow_plan_device(dev.data_ptr(), pairs, "perspective", (1920, 1080), (960, 540), 0.5, 16.0, 0.7, False)
+        final_dev, path_dev, target_dev, _ = ctx.flow_plan_result(pairs + 1, 8)
+        plan = fp.plan_stabilization(ctx, table, (1920, 1080), pairs + 1, "crop_and_pad", "perspective", False, 0.7, 0.5, 0.6,
+                                     (127, 127, 127), 16.0, 16.0)
+        assert np.array_equal(path_dev, plan.estimated_motion["path"]), case
+        assert np.array_equal(target_dev, plan.estimated_motion["target_path"]), case
+        # final = T @ M: sums of two inexact terms, whose float32 rounding is NumPy's matmul's business (fused or not): equal to a
+        # few units in the last place here, bit-equal for nearly every frame (what is not is warped again by the pipeline)
+        assert np.abs(final_dev.astype(np.float64) - plan.final_matrices).max() <= 1e-4 * 2.0 ** -20, case
+        differing = int((final_dev.view(np.uint32) != plan.final_matrices.view(np.uint32)).reshape(pairs + 1, -1).any(axis=1).sum())
+        assert differing <= 2, (case, differing)
 
 
 @pytest.mark.parametrize("mode", ["similarity", "translation"])
@@ -226,7 +307,7 @@ def test_sticky_mode_on_the_device_equals_the_host_walk(ctx, pkg, mode):
             table[30, 0]["accepted"] = 0
         dev = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).to(ctx.device)
         ctx.flow_plan_device(dev.data_ptr(), pairs, mode, (1920, 1080), (960, 540), 0.5, 16.0, 0.7, False)
-        final_dev = ctx.flow_plan_result(pairs + 1, 4 if mode == "similarity" else 2)[0]
+        final_dev = ctx.flow_plan_result(pairs + 1, fp.PLAN_PARAMS[mode])[0]
         plan = fp.plan_stabilization(ctx, table, (1920, 1080), pairs + 1, "crop_and_pad", mode, False, 0.7, 0.5, 0.6,
                                      (127, 127, 127), 16.0, 16.0)
         # A wrong choice anywhere would move entries by ~1e-3.  Bit equality is NOT asserted here: after a fallback to
