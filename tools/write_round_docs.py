@@ -104,6 +104,10 @@ C5's output canvas: {shape[2]}x{shape[1]} (expand).  Both chains are the blur wa
 samples too (blur warp 37.1 -> ~36 ms; the per-pixel fp64 reciprocal of the denominator is the contract and stays).  Parity at these sizes:
 `tests/test_configs_gpu.py` (C3: all 255 pairs + blurred frames {{0, 1, 127, 254, 255}}; C5: all 63 pairs, warped frames {{0, 31, 63}}, blurred
 frames {{0, 1, 31, 62, 63}}, bit-exact against the oracle).
+
+Device plan of the chains' Flow halves (the plan between the fits and the warp formed by `plan_kernel`, verified by the host): C3
+(perspective) {c3p["config"].get("rank0_device_plan")}, C5 (similarity, expand) {c5p["config"].get("rank0_device_plan")}.  C3 with the plan on the
+host / on the device, one box, alternating (`tools/r05_c3ab.sh`): 47.42 / 46.85 / 47.02 / 47.02 ms per step.
 """)
 
 c4, d1 = line(f"{TAG}_c4_single_gpu.log"), line(f"{TAG}_c4_dist1_128.log")
