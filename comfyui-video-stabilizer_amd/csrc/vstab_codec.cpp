@@ -2,6 +2,7 @@
 // compiler, each loop in a baseline and an AVX2 build of the same source, chosen once at run time.
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -32,7 +33,8 @@ __attribute__((target("avx2"))) bool encode_avx2(const float* __restrict__ src, 
 void expand_base(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) { VSTAB_EXPAND_BODY }
 __attribute__((target("avx2"))) void expand_avx2(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) { VSTAB_EXPAND_BODY }
 
-const bool have_avx2 = __builtin_cpu_supports("avx2");
+// VSTAB_CODEC_BASELINE=1 (tests): the baseline build of the loops on a machine that has AVX2
+const bool have_avx2 = __builtin_cpu_supports("avx2") && !(getenv("VSTAB_CODEC_BASELINE") && atoi(getenv("VSTAB_CODEC_BASELINE")) != 0);
 
 }  // namespace
 

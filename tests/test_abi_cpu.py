@@ -537,6 +537,19 @@ def test_shipped_library_has_no_fault_injectors(pkg):
     assert out.stdout.strip() == "1", out.stderr[-2000:]
 
 
+def test_coded_transfer_host_loops_baseline_build():
+    """The same checks on the loops' baseline (SSE2) build, which a machine with AVX2 never runs otherwise: a child process with
+    VSTAB_CODEC_BASELINE=1 (the choice is made when the library is loaded)."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VSTAB_CODEC_BASELINE="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", f"{__file__}::test_coded_transfer_host_loops"], env=env,
+                         capture_output=True, text=True, cwd=str(Path(__file__).resolve().parents[1]))
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-800:] + out.stderr[-400:]
+
+
 def test_coded_transfer_host_loops(pkg):
     """The host halves of the coded node-boundary transfers (csrc/vstab_codec.cpp, called by vstab_upload_f32_coded /
     vstab_download_mask_coded): a run of values is accepted for the byte form only if EVERY value has exactly the bits of
