@@ -304,6 +304,10 @@ class Context:
         handle = C.c_void_p()
         _check(self.lib.vstab_create(C.byref(handle), self.device_index), "vstab_create")
         self.handle = handle
+        # what the most recent node-boundary transfers did (upload / download below): chunks that crossed PCIe as bytes of
+        # all chunks; whether the mask came back as bytes
+        self.last_upload_coded = (0, 0)
+        self.last_download_coded = False
         self.use_torch_stream()
 
     def close(self) -> None:
