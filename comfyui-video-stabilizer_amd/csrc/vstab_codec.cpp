@@ -34,6 +34,12 @@ void expand_base(const unsigned char* __restrict__ src, float* __restrict__ dst,
 __attribute__((target("avx2"))) void expand_avx2(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) { VSTAB_EXPAND_BODY }
 
 // VSTAB_CODEC_BASELINE=1 (tests): the baseline build of the loops on a machine that has AVX2
+#define VSTAB_LEVELS_BODY \
+    for (size_t i = 0; i < n; i++) dst[i] = lut[src[i]];
+
+void levels_base(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n, const float* __restrict__ lut) { VSTAB_LEVELS_BODY }
+__attribute__((target("avx2"))) void levels_avx2(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n, const float* __restrict__ lut) { VSTAB_LEVELS_BODY }
+
 const bool have_avx2 = __builtin_cpu_supports("avx2") && !(getenv("VSTAB_CODEC_BASELINE") && atoi(getenv("VSTAB_CODEC_BASELINE")) != 0);
 
 }  // namespace
@@ -41,3 +47,5 @@ const bool have_avx2 = __builtin_cpu_supports("avx2") && !(getenv("VSTAB_CODEC_B
 // (C linkage so that the CPU test suite can call the two loops through ctypes; not part of include/vstab.h)
 extern "C" bool vstab_host_encode_q8(const float* src, unsigned char* dst, size_t n) { return have_avx2 ? encode_avx2(src, dst, n) : encode_base(src, dst, n); }
 extern "C" void vstab_host_expand_mask(const unsigned char* src, float* dst, size_t n) { have_avx2 ? expand_avx2(src, dst, n) : expand_base(src, dst, n); }
+// bytes c -> lut[c] (a soft mask's levels: the float32 values 1 - c / S of the motion-blur warp, formed by the caller)
+extern "C" void vstab_host_expand_levels(const unsigned char* src, float* dst, size_t n, const float* lut) { have_avx2 ? levels_avx2(src, dst, n, lut) : levels_base(src, dst, n, lut); }

@@ -250,6 +250,8 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
 extern "C" bool vstab_host_encode_q8(const float* src, unsigned char* dst, size_t n);
 // bytes -> 0.0f / 1.0f
 extern "C" void vstab_host_expand_mask(const unsigned char* src, float* dst, size_t n);
+// bytes c -> lut[c]
+extern "C" void vstab_host_expand_levels(const unsigned char* src, float* dst, size_t n, const float* lut);
 
 namespace {
 
@@ -297,6 +299,36 @@ __global__ __launch_bounds__(256) void pack_mask_kernel(const float* __restrict_
         const unsigned b = reinterpret_cast<const unsigned*>(src)[i];
         odd |= (b != 0u) & (b != 0x3f800000u);
         dst[i] = b != 0u;
+    }
+    if (__ballot(odd != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(other, 1);
+}
+
+// The motion-blur warp's mask is 1 - c / S for c = 0 .. S covered samples, values below 1e-3 set to 0 (vstab_warp.hip,
+// nodes/motion_apply.py:195-199): S + 1 different floats.  value -> c; *other is raised if a value is not one of them by its bits.
+__device__ __forceinline__ float level_value(int c, float fs)
+{
+    const float m = 1.0f - (float)c / fs;
+    return (m < 1e-3f) ? 0.f : m;
+}
+
+__global__ __launch_bounds__(256) void pack_levels_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t n, int levels, int* other)
+{
+    const float fs = (float)levels;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned odd = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += stride) {
+        unsigned pack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t j = 4 * i + k;
+            const float m = j < n ? src[j] : 1.0f;
+            const float t = (1.0f - m) * fs + 0.5f;
+            int c = (t >= 0.f && t <= fs + 1.0f) ? (int)t : 0;     // NaN: 0, caught by the comparison below
+            c = c > levels ? levels : c;
+            odd |= __float_as_uint(level_value(c, fs)) != __float_as_uint(m);
+            pack |= (unsigned)c << (8 * k);
+        }
+        reinterpret_cast<unsigned*>(dst)[i] = pack;       // (dst holds a multiple of 16 bytes)
     }
     if (__ballot(odd != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(other, 1);
 }
@@ -399,10 +431,25 @@ extern "C" int vstab_upload_u8_as_f32(vstab_ctx* ctx, const unsigned char* host_
     return upload_as_bytes<false>(ctx, host_src, dev_dst, count, &done, "vstab_upload_u8_as_f32");
 }
 
+static int download_mask_levels(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int levels, int* coded);
+
 extern "C" int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded)
 {
     VSTAB_REQUIRE(ctx != nullptr, "vstab_download_mask_coded: ctx is NULL");
     VSTAB_REQUIRE(count == 0 || (dev_src && host_dst), "vstab_download_mask_coded: NULL pointer argument");
+    return download_mask_levels(ctx, dev_src, host_dst, count, 1, coded);
+}
+
+extern "C" int vstab_download_mask_levels(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int levels, int* coded)
+{
+    VSTAB_REQUIRE(ctx != nullptr, "vstab_download_mask_levels: ctx is NULL");
+    VSTAB_REQUIRE(count == 0 || (dev_src && host_dst), "vstab_download_mask_levels: NULL pointer argument");
+    VSTAB_REQUIRE(levels >= 1 && levels <= 255, "vstab_download_mask_levels: levels=%d (1 .. 255)", levels);
+    return download_mask_levels(ctx, dev_src, host_dst, count, levels, coded);
+}
+
+static int download_mask_levels(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int levels, int* coded)
+{
     if (coded) *coded = 0;
     if (count == 0) return 0;
     VSTAB_HIP(hipSetDevice(ctx->device));
@@ -420,7 +467,13 @@ extern "C" int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, f
     VSTAB_HIP(hipEventRecord(ctx->ev_xfer_sync, ctx->xfer_stream));
     VSTAB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_xfer_sync, 0));
     *other = 0;
-    hipLaunchKernelGGL(pack_mask_kernel, dim3(grid_for(count / 16)), dim3(256), 0, ctx->stream, dev_src, packed, count, d_other);
+    float lut[256];
+    for (int c = 0; c < 256; c++) {       // the host's float32 arithmetic of level_value (IEEE division and subtraction on both sides)
+        const float m = 1.0f - (float)(c <= levels ? c : levels) / (float)levels;
+        lut[c] = (m < 1e-3f) ? 0.f : m;
+    }
+    if (levels == 1) hipLaunchKernelGGL(pack_mask_kernel, dim3(grid_for(count / 16)), dim3(256), 0, ctx->stream, dev_src, packed, count, d_other);
+    else hipLaunchKernelGGL(pack_levels_kernel, dim3(grid_for(count / 16)), dim3(256), 0, ctx->stream, dev_src, packed, count, levels, d_other);
     VSTAB_HIP(hipGetLastError());
     VSTAB_HIP(hipStreamSynchronize(ctx->stream));
     if (vstab_check_device_status(ctx, "vstab_download_mask_coded")) return 3;
@@ -455,7 +508,9 @@ extern "C" int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, f
             if (!team.failed) {
                 size_t lo, hi;
                 team.share(me, len, lo, hi);
-                if (hi > lo) vstab_host_expand_mask(reinterpret_cast<const unsigned char*>(r.slot[s]) + lo, host_dst + off + lo, hi - lo);
+                const unsigned char* q = reinterpret_cast<const unsigned char*>(r.slot[s]) + lo;
+                if (hi > lo && levels == 1) vstab_host_expand_mask(q, host_dst + off + lo, hi - lo);
+                else if (hi > lo) vstab_host_expand_levels(q, host_dst + off + lo, hi - lo, lut);
             }
             team.sync();
         }

@@ -273,8 +273,9 @@ def _normalize_video_input(value: Any) -> VideoContext:
     return VideoContext(frames, first, int(w), int(h), int(c), fps, kind, tmeta)
 
 
-def _to_host(t, mask=False):
-    """Device tensor -> CPU tensor (mask=True: a float32 padding mask, which may cross PCIe as bytes: Context.download).  With VSTAB_PINNED_OUTPUT=1 the result lives in page-locked memory and is filled by
+def _to_host(t, mask=False, levels=1):
+    """Device tensor -> CPU tensor (mask=True: a float32 padding mask, which may cross PCIe as bytes: Context.download; levels: the
+    samples S of a motion-blurred mask, 1 for a 0 / 1 mask).  With VSTAB_PINNED_OUTPUT=1 the result lives in page-locked memory and is filled by
     one direct DMA (2-3x the rate of the pageable path, which bounces through a staging buffer); the tensor is an
     ordinary CPU tensor for every consumer, but keeps its pages locked while it lives -- hence opt-in."""
     import os
@@ -291,7 +292,7 @@ def _to_host(t, mask=False):
     from . import native
 
     with torch.cuda.device(t.device):
-        return native.default_context().download(t, mask=mask)
+        return native.default_context().download(t, mask=mask, levels=levels)
 
 
 def _reconstruct_video(frames: Any, context: VideoContext) -> Any:
@@ -314,13 +315,13 @@ def _reconstruct_video(frames: Any, context: VideoContext) -> Any:
     return out
 
 
-def _convert_masks_for_output(masks: Any) -> Any:
+def _convert_masks_for_output(masks: Any, levels: int = 1) -> Any:
     """(N,h,w,1)|(N,h,w) -> (N,h,w) float32 (stabilizer_utils.py:1055-1077)."""
     if torch is not None and isinstance(masks, torch.Tensor):
         if masks.shape[0] == 0:
             return torch.zeros((1, 1, 1), dtype=torch.float32)
         m = masks[..., 0] if masks.ndim == 4 else masks
-        return _to_host(m.to(dtype=torch.float32).contiguous(), mask=True)
+        return _to_host(m.to(dtype=torch.float32).contiguous(), mask=True, levels=levels)
     if isinstance(masks, np.ndarray) and masks.ndim in (3, 4):
         stacked = np.zeros((1, 1, 1), np.float32) if not masks.shape[0] else (masks[..., 0] if masks.ndim == 4 else masks)
     else:

@@ -110,6 +110,7 @@ _SIGNATURES = {
     "vstab_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vstab_upload_f32_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vstab_upload_u8_as_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vstab_download_mask_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
     "vstab_download_mask_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "vstab_warp_batch": (
         C.c_int,
@@ -414,17 +415,19 @@ class Context:
         _check(self.lib.vstab_upload_u8_as_f32(self.handle, src.data_ptr(), _dev_ptr(dst), src.numel()), "vstab_upload_u8_as_f32")
         return dst
 
-    def download(self, device_tensor, mask=False):
+    def download(self, device_tensor, mask=False, levels=1):
         """Device tensor -> new CPU tensor (pageable, as the reference returns) through the pinned ring (vstab_download).
-        mask=True (a float32 padding mask): vstab_download_mask_coded -- a mask of zeros and ones crosses as bytes and is
-        expanded by the host threads, any other mask takes the plain path.  `last_download_coded` tells which."""
+        mask=True (a float32 padding mask): vstab_download_mask_levels -- a mask of zeros and ones (levels = 1), or the motion-blur
+        warp's 1 - c / S (levels = S samples), crosses as bytes and is expanded by the host threads; a mask with any other value
+        takes the plain path.  `last_download_coded` tells which."""
         torch = self.torch
         src = device_tensor.contiguous()
         dst = torch.empty(src.shape, dtype=src.dtype)
         self.use_torch_stream()
         if mask and src.dtype == torch.float32 and _coded_transfers():
             coded = C.c_int(0)
-            _check(self.lib.vstab_download_mask_coded(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel(), C.byref(coded)), "vstab_download_mask_coded")
+            _check(self.lib.vstab_download_mask_levels(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel(), max(1, min(255, int(levels))),
+                                                       C.byref(coded)), "vstab_download_mask_levels")
             self.last_download_coded = bool(coded.value)
         else:
             _check(self.lib.vstab_download(self.handle, _dev_ptr(src), dst.data_ptr(), src.numel() * src.element_size()), "vstab_download")

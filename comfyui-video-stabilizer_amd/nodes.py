@@ -36,10 +36,11 @@ def _image_out(frames, context):
     return hm._reconstruct_video(frames, context)
 
 
-def _mask_out(masks):
+def _mask_out(masks, levels: int = 1):
+    """levels: the motion-blur samples S behind a soft mask (its values are 1 - c / S: they may cross PCIe as bytes), 1 otherwise."""
     if _keep_on_device() and hasattr(masks, "device"):
         return masks[..., 0] if masks.ndim == 4 else masks
-    return hm._convert_masks_for_output(masks)
+    return hm._convert_masks_for_output(masks, levels)
 
 
 def _estimator_inputs(transform_tip: str, lock_tip: str, framing_tip: str, strength_tip: str, smooth_tip: str) -> list:
@@ -205,7 +206,9 @@ class VideoStabilizerMotionApply(io.ComfyNode):
                               motion_blur_samples=samples, progress_callback=tick, keep_on_device=True)
         result.meta.setdefault("motion_apply", {})["motion_blur_quality"] = quality
         pbar.update_absolute(total, total)
-        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks), result.meta)
+        ma = result.meta.get("motion_apply", {})
+        levels = int(ma.get("motion_blur_samples", 1)) if float(ma.get("motion_blur", 0.0)) > 0.0 else 1
+        return io.NodeOutput(_image_out(result.frames, context), _mask_out(result.masks, levels), result.meta)
 
 
 class VideoStabilizerInverse(io.ComfyNode):

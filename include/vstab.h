@@ -98,6 +98,11 @@ int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_dst, size_t b
 int vstab_upload_f32_coded(vstab_ctx* ctx, const float* host_src, float* dev_dst, size_t count, size_t* coded_chunks);
 int vstab_upload_u8_as_f32(vstab_ctx* ctx, const unsigned char* host_src, float* dev_dst, size_t count);
 int vstab_download_mask_coded(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int* coded);
+/* The motion-blur warp's soft mask (nodes/motion_apply.py:195-199) holds 1 - c / S for c = 0 .. S covered samples, values below
+ * 1e-3 set to 0: S + 1 different floats.  vstab_download_mask_levels(levels = S) sends c as a byte and the host threads look the
+ * float up (formed with the same IEEE float32 subtraction and division); a mask with any other value takes vstab_download.
+ * levels = 1 is vstab_download_mask_coded. */
+int vstab_download_mask_levels(vstab_ctx* ctx, const float* dev_src, float* host_dst, size_t count, int levels, int* coded);
 
 /* ---- F13 / A3: per-frame warp with padding mask ---------------------------
  * Replaces the loop at nodes/video_stabilizer_flow.py:560-588 and

@@ -578,6 +578,14 @@ def test_coded_transfer_host_loops(pkg):
         back = np.empty(n, np.float32)
         exp(k.ctypes.data, back.ctypes.data, n)
         assert np.array_equal(back.view(np.uint32), np.where(k != 0, np.float32(1.0), np.float32(0.0)).view(np.uint32))
+    lev = lib.vstab_host_expand_levels
+    lev.restype, lev.argtypes = None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lut = rng.random(256).astype(np.float32)
+    for n in (1, 31, 1000, 4099):
+        c = rng.integers(0, 256, n).astype(np.uint8)
+        got = np.empty(n, np.float32)
+        lev(c.ctypes.data, got.ctypes.data, n, lut.ctypes.data)
+        assert np.array_equal(got.view(np.uint32), lut[c].view(np.uint32))
     # every quotient, and both of its float32 neighbours (never a quotient themselves)
     q = np.arange(256, dtype=np.float32) / np.float32(255.0)
     out = np.empty(256, np.uint8)

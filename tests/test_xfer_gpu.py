@@ -162,3 +162,51 @@ def test_uint8_clips_through_the_nodes_equal_their_float_form(pkg, ctx):
         a = nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(u8), meta, "crop_and_pad", "bilinear", "#7F7F7F", blur, quality)
         b = nodes.VideoStabilizerMotionApply.execute(torch.from_numpy(f32), meta, "crop_and_pad", "bilinear", "#7F7F7F", blur, quality)
         assert torch.equal(bits(a[0]), bits(b[0])) and torch.equal(bits(a[1]), bits(b[1]))
+
+
+def soft_mask(n, levels, seed):
+    """What warp_blur_kernel writes: 1 - c / S in float32 for c = 0 .. S covered samples, values below 1e-3 set to 0."""
+    import torch
+
+    c = torch.randint(0, levels + 1, (n,), generator=torch.Generator().manual_seed(seed), dtype=torch.int32).numpy()
+    m = np.float32(1.0) - c.astype(np.float32) / np.float32(levels)
+    m[m < np.float32(1e-3)] = 0.0
+    return torch.from_numpy(m)
+
+
+@pytest.mark.parametrize("levels", [1, 3, 5, 9, 17, 33])
+@pytest.mark.parametrize("n", [(1 << 20) + 5, (32 << 20) + 17])
+def test_soft_mask_levels_cross_as_bytes(ctx, levels, n):
+    """vstab_download_mask_levels: the S + 1 values of a motion-blurred mask come back with their bits; the same mask declared with
+    another S, or with one value off by an ulp, takes the plain path (and still comes back with its bits)."""
+    import torch
+
+    host = soft_mask(n, levels, levels)
+    back = ctx.download(host.cuda(), mask=True, levels=levels)
+    assert ctx.last_download_coded is True and torch.equal(bits(back), bits(host))
+    if levels > 1:
+        other = ctx.download(host.cuda(), mask=True, levels=levels - 1 if levels != 3 else 7)
+        assert ctx.last_download_coded is False and torch.equal(bits(other), bits(host))
+        m = host.clone()
+        pos = int(torch.nonzero((m > 0) & (m < 1))[0])
+        m[pos] = torch.nextafter(m[pos], torch.tensor(2.0))
+        again = ctx.download(m.cuda(), mask=True, levels=levels)
+        assert ctx.last_download_coded is False and torch.equal(bits(again), bits(m))
+
+
+def test_motion_apply_node_sends_its_soft_mask_as_bytes(pkg, ctx, monkeypatch):
+    import torch
+
+    from tests.util import synth_frames
+    from vstab_amd import nodes
+
+    frames = torch.from_numpy(synth_frames(6, 540, 960, seed=8))
+    meta = nodes.VideoStabilizerFlow.execute(frames, 16.0, "crop_and_pad", "similarity", False, 0.7, 0.5, 0.6, "#7F7F7F")[2]
+    out = nodes.VideoStabilizerMotionApply.execute(frames, meta, "crop_and_pad", "bicubic", "#7F7F7F", 0.5, "High")
+    assert ctx.last_download_coded is True
+    soft = out[1]
+    assert float(soft.max()) <= 1.0 and bool(((soft > 0) & (soft < 1)).any())          # a genuinely soft mask
+    monkeypatch.setenv("VSTAB_XFER_CODED", "0")
+    ref = nodes.VideoStabilizerMotionApply.execute(frames, meta, "crop_and_pad", "bicubic", "#7F7F7F", 0.5, "High")
+    assert ctx.last_download_coded is False
+    assert torch.equal(bits(out[0]), bits(ref[0])) and torch.equal(bits(out[1]), bits(ref[1])) and out[2] == ref[2]
