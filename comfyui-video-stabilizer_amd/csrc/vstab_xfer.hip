@@ -240,11 +240,13 @@ extern "C" int vstab_download(vstab_ctx* ctx, const void* dev_src, void* host_ds
 //  * a ComfyUI IMAGE decoded from 8-bit video holds float32(k) / float32(255), k = 0 .. 255, and nothing else
 //    (`np.array(img).astype(np.float32) / 255.0`).  The staging threads look at every value they copy anyway: a chunk whose
 //    values ALL have exactly the bits of such a quotient crosses as bytes (a quarter of the traffic) and is expanded by
-//    a kernel with the same correctly rounded float32 division; any other chunk crosses as float32, and after the first such
-//    chunk the call stops trying.  The device tensor has the source's bits either way.
-//  * the Flow node's padding mask is 0.0f or 1.0f per pixel (nodes/video_stabilizer_flow.py:583-586): a kernel packs it
-//    to bytes and reports whether every value was one of the two; if so the bytes cross and the host threads expand
-//    them, else (Motion Apply's soft mask under motion blur) the plain download runs.
+//    a kernel with the same correctly rounded float32 division; the first chunk with any other value, and everything
+//    behind it, crosses as float32 (vstab_upload).  The device tensor has the source's bits either way.  A uint8 clip
+//    (nodes/stabilizer_utils.py:122-126) takes the same road without the test: its bytes ARE the k.
+//  * the Flow node's padding mask is 0.0f or 1.0f per pixel (nodes/video_stabilizer_flow.py:583-586), Motion Apply's under
+//    motion blur 1 - c / S for c = 0 .. S covered samples (nodes/motion_apply.py:195-199): a kernel packs the mask to bytes
+//    and reports whether every value was one of those; if so the bytes cross and the host threads expand them, else the
+//    plain download runs.
 // vstab_codec.cpp (host loops, baseline + AVX2 builds of the same source):
 // values -> bytes; false (output unspecified) unless every value has exactly the bits of float32(k) / 255.0f, k = 0 .. 255
 extern "C" bool vstab_host_encode_q8(const float* src, unsigned char* dst, size_t n);
