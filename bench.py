@@ -569,12 +569,13 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
     agree(alloc_ok, "allocating the clip")
     stats: dict = {}
     lap = {"flow": 0.0, "apply": 0.0}
-    plan_seen: list = []   # the Flow half's device-plan verdict per step ({"used", "mismatched_frames"}; sharded: in stats)
+    plan_seen: list = []   # the Flow half's device-plan verdict per step ({"used", "mismatched_frames"})
 
     def step():
         t0 = time.perf_counter()
         if use_dist:
             _, _, meta = vd.stabilize_sharded(ctx, frames, total, *C5_FLOW_ARGS, stats=stats, want_meta=True)
+            plan_seen.append(stats.get("device_plan"))
             t1 = time.perf_counter()
             out = vd.apply_motion_sharded(ctx, frames[halo:], start, total, meta, (127, 127, 127), **C5_APPLY)
         else:
@@ -635,7 +636,7 @@ def run_c5(ctx, torch, dist, device, rank, world, use_dist, total, h, w, steps, 
            "rank0_stage_ms": stage_ms,
            "rank0_device_plan": ({"used": all(bool(v and v.get("used")) for v in plan_seen),
                                   "mismatched_frames_max_per_step": max(int((v or {}).get("mismatched_frames", 0)) for v in plan_seen)}
-                                 if plan_seen else stats.get("device_plan")),
+                                 if plan_seen else None),
            "rank0_host_ms": {"flow_half": round(lap["flow"] / steps * 1e3, 3), "apply_half_launch": round(lap["apply"] / steps * 1e3, 3),
                              **{k: round(v / steps, 3) for k, v in stats.items() if isinstance(v, (int, float))}},
            "sharding": "single GPU" if world == 1 else f"contiguous frame shards x{world}, 1-frame halo for the Flow half, RCCL all-gather "
