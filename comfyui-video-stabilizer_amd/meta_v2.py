@@ -96,6 +96,12 @@ def _matrices_checked(owner: str, entries: list, key: str) -> List[np.ndarray]:
 
 def validate_motion_meta(block: Dict[str, Any]) -> None:
     """motion_meta.py:62-100."""
+    _validated_matrices(block)
+
+
+def _validated_matrices(block: Dict[str, Any]) -> List[np.ndarray]:
+    """validate_motion_meta, handing back the per-frame matrices it had to form for the check (the parser needs them next: a
+    256-frame block's nested lists are walked once instead of twice)."""
     if not isinstance(block, dict):
         raise ValueError("motion_meta must be an object.")
     if block.get("version") != 2:
@@ -128,9 +134,10 @@ def validate_motion_meta(block: Dict[str, Any]) -> None:
         raise ValueError(
             "motion_meta.frame_count mismatch: " f"frame_count is {count}, per_frame has {len(entries)} entry/entries."
         )
-    _matrices_checked("motion_meta", entries, "matrix")
+    matrices = _matrices_checked("motion_meta", entries, "matrix")
     if source == "generated_shake" and not isinstance(block.get("generator"), dict):
         raise ValueError("motion_meta.generator is required when source is 'generated_shake'.")
+    return matrices
 
 
 def build_motion_meta_v2(*, source: str, frame_count: int, fps: float, input_size: Tuple[int, int],
@@ -225,9 +232,7 @@ def applied_motion_meta_from_stabilization_warp(warp_meta: Dict[str, Any], fps: 
 
 
 def _parse_block(block: Dict[str, Any]) -> MotionMeta:
-    validate_motion_meta(block)
-    frames = [FrameTransform(index=pos, matrix=m)
-              for pos, m in enumerate(_matrices_checked("motion_meta", block["per_frame"], "matrix"))]
+    frames = [FrameTransform(index=pos, matrix=m) for pos, m in enumerate(_validated_matrices(block))]
     gen = block.get("generator")
     return MotionMeta(
         source=str(block["source"]),
