@@ -229,11 +229,19 @@ def apply_motion(
     keep_on_device: bool = False,
 ) -> MotionApplyResult:
     """Signature of the reference's apply_motion (motion_apply.py:297-307) plus GPU-context extras."""
-    motion = _resolve_motion_for_context(meta, context)
-    _validate_context(context, motion)
-    _check_interpolation(interpolation)
-    if ("crop_and_pad" if framing_mode == "pad" else framing_mode) not in ("crop_and_pad", "crop", "expand"):
-        raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop_and_pad', 'crop', or 'expand'.")
+    def checked_motion():
+        motion = _resolve_motion_for_context(meta, context)
+        _validate_context(context, motion)
+        _check_interpolation(interpolation)
+        if ("crop_and_pad" if framing_mode == "pad" else framing_mode) not in ("crop_and_pad", "crop", "expand"):
+            raise ValueError(f"Unsupported framing_mode {framing_mode!r}; expected 'crop_and_pad', 'crop', or 'expand'.")
+        return motion
+
+    # Frames that are already on the device (a Flow -> Motion Apply chain with device-resident sockets): the range pass below is
+    # launched BEFORE the meta is parsed and validated (0.4 ms of host work for 256 frames, during which the GPU had nothing to
+    # do: tools/chain_timeline.py).  Host frames: validation first -- a bad meta must not cost an upload.
+    resident = context.batch is not None and getattr(context.batch, "device", None) is not None and context.batch.device.type == "cuda"
+    motion = None if resident else checked_motion()
     ctx = ctx or native.default_context()
     device_frames = context.device_batch(ctx)
     kw = dict(framing_mode=framing_mode, interpolation=interpolation, motion_blur=motion_blur, motion_blur_samples=motion_blur_samples)
@@ -250,11 +258,13 @@ def apply_motion(
             with torch.cuda.stream(side):
                 peaks = hm.prefetch_peaks(ctx.frame_range(device_frames))
             peaks.record_stream(main)   # allocated from the side stream's pool, consumed on the main stream below
+            if motion is None:
+                motion = checked_motion()
             frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
                                                                 progress_callback=progress_callback, **kw)
         finally:
-            # also when the warp raised (validation, VstabError, a cancel delivered by a progress tick): the maxima
-            # pass still reads the frames, and the caller is free to drop them as soon as this frame unwinds
+            # also when the validation or the warp raised (a bad meta, VstabError, a cancel delivered by a progress tick): the
+            # maxima pass still reads the frames, and the caller is free to drop them as soon as this frame unwinds
             main.wait_stream(side)
         if hm.resolve_value_range(context, peaks, ctx):
             check_interrupt()
@@ -262,6 +272,8 @@ def apply_motion(
             frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
                                                                 progress_callback=None, **kw)
     else:
+        if motion is None:
+            motion = checked_motion()
         frames, masks, result_meta = apply_motion_on_device(ctx, device_frames, 0, motion, meta, padding_rgb,
                                                             progress_callback=progress_callback, **kw)
     check_interrupt()

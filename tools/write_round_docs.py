@@ -108,6 +108,12 @@ frames {{0, 1, 31, 62, 63}}, bit-exact against the oracle).
 Device plan of the chains' Flow halves (the plan between the fits and the warp formed by `plan_kernel`, verified by the host): C3
 (perspective) {c3p["config"].get("rank0_device_plan")}, C5 (similarity, expand) {c5p["config"].get("rank0_device_plan")}.  C3 with the plan on the
 host / on the device, one box, alternating (`tools/r05_c3ab.sh`): 47.42 / 46.85 / 47.02 / 47.02 ms per step.
+
+Where the GPU idles inside one step of a chain (`tools/r05_chain_timeline.sh`, kernel trace): between the Flow half's warp and Motion Apply's
+first launch, while the host finishes Flow's meta and parses it again for Motion Apply.  With device-resident frames Motion Apply now launches its
+range pass BEFORE it parses and validates the meta (host frames keep validation first: a bad meta must not cost an upload): idle per step C3 519 ->
+237 us (the gap in front of the range pass 420 -> 149 us), C5 372 -> 294 us (185 -> 119 us; its other gap, 73-77 us, is the wait for the plan's
+region that sizes the expand canvas).
 """)
 
 c4, d1 = line(f"{TAG}_c4_single_gpu.log"), line(f"{TAG}_c4_dist1_128.log")
