@@ -159,9 +159,13 @@ def _center_crop_matrix_from_common(common: np.ndarray, output_size: Tuple[int, 
 
 def _expand_matrices(matrices: List[np.ndarray], input_size: Tuple[int, int]):
     """motion_apply.py:288-294."""
-    mins, maxs = hm._compute_bounding_boxes(matrices, input_size[0], input_size[1])
+    # (one batched matmul each instead of a Python loop over the frames: every rank of a sharded replay evaluates the WHOLE
+    # clip's matrices here -- 512 frames of C5 took 3.6 ms per rank and step in front of the blur warp's launch; same bits:
+    # tests/test_host_golden.py)
+    stack = np.stack([np.asarray(m, dtype=np.float64) for m in matrices])
+    mins, maxs = hm.bounding_boxes_batched(stack, input_size[0], input_size[1])
     shift, output_size = hm._prepare_expand_transform(mins, maxs)
-    return [shift @ m for m in matrices], output_size
+    return list(np.matmul(shift, stack)), output_size
 
 
 def apply_motion_on_device(ctx, device_frames, first: int, motion: MotionMeta, meta: Dict[str, Any], padding_rgb, *,

@@ -14,6 +14,7 @@ from typing import Any, Dict, Sequence, Tuple
 import numpy as np
 
 from . import host_math as hm
+from . import native
 
 
 def _largest_aspect_ratio_rectangle(binary_mask: np.ndarray, target_width: int, target_height: int):
@@ -62,8 +63,10 @@ def _largest_aspect_ratio_rectangle(binary_mask: np.ndarray, target_width: int, 
 def _bbox_candidate(delta_params, base_mode, width, height, scale, safety_margin_px) -> Tuple[float, Dict[str, Any]]:
     """evaluate_bbox_only (stabilizer_utils.py:551-609): crop from the intersection of the warped frame bounds."""
     s = float(np.clip(scale, 0.0, 1.0))
-    mats = [hm._params_to_matrix(d * s, base_mode) for d in delta_params]
-    mins, maxs = hm._compute_bounding_boxes(mats, width, height)
+    # one library call each over the clip (vstab_params_to_matrices, vstab_bounding_boxes: the per-item forms' arithmetic, pinned to
+    # them by tests/test_abi_cpu.py) instead of two Python loops over the frames per bisection step -- up to nineteen steps
+    mats = native.params_to_matrices(np.asarray(delta_params, dtype=np.float64) * s, base_mode)
+    mins, maxs = native.bounding_boxes(mats, width, height)
     x0, y0 = float(np.max(mins[:, 0])), float(np.max(mins[:, 1]))
     x1, y1 = float(np.min(maxs[:, 0])), float(np.min(maxs[:, 1]))
     safe_w, safe_h = max(0.0, x1 - x0), max(0.0, y1 - y0)
@@ -79,7 +82,7 @@ def _bbox_candidate(delta_params, base_mode, width, height, scale, safety_margin
     cy0 = safe_y0 + (safe_h - crop_h) * 0.5
     cs = width / crop_w
     crop = np.array([[cs, 0.0, -cs * cx0], [0.0, cs, -cs * cy0], [0.0, 0.0, 1.0]], dtype=np.float32)
-    return ratio, {"scale": scale, "pre_crop": mats, "final": [crop @ m for m in mats], "crop_origin": [cx0, cy0],
+    return ratio, {"scale": scale, "pre_crop": mats, "final": np.matmul(crop, mats), "crop_origin": [cx0, cy0],
                    "crop_size": [crop_w, crop_h], "has_overlap": True}
 
 
@@ -158,7 +161,7 @@ def solve_crop(ctx, base_mode: str, delta_params: Sequence[np.ndarray], width: i
             x0, y0, crop_w, crop_h = rect
             cs = width / crop_w
             crop = np.array([[cs, 0.0, -cs * x0], [0.0, cs, -cs * y0], [0.0, 0.0, 1.0]], dtype=np.float32)
-            refined = [crop @ m for m in final]
+            refined = list(np.matmul(crop, np.stack(final)))
             crop_origin, crop_size, keep_effective = [x0, y0], [crop_w, crop_h], 1.0
     return {
         "final_matrices": refined,

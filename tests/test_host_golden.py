@@ -226,6 +226,19 @@ def test_batched_host_math_equals_per_item(hm):
     assert np.array_equal(mins, bmins) and np.array_equal(maxs, bmaxs)
     shift = np.array([[1, 0, 3.25], [0, 1, -7.5], [0, 0, 1]], np.float32)
     assert np.array_equal(np.matmul(shift, stack), np.stack([shift @ m for m in stack]))
+    # Motion Apply's matrices are float64 (parsed from the meta, or the inverse of a recorded warp): the expand geometry of
+    # apply_pipeline._expand_matrices on such a stack, batched against per item
+    s64 = stack.astype(np.float64) + rng.uniform(-1e-9, 1e-9, stack.shape)
+    s64[:, 2, 2] = 1.0
+    mins, maxs = hm._compute_bounding_boxes(list(s64), 3840, 2160)
+    bmins, bmaxs = hm.bounding_boxes_batched(s64, 3840, 2160)
+    assert np.array_equal(mins, bmins) and np.array_equal(maxs, bmaxs)
+    sh, size = hm._prepare_expand_transform(mins, maxs)
+    assert np.array_equal(np.matmul(sh, s64), np.stack([sh @ m for m in s64])) and np.matmul(sh, s64).dtype == np.float64
+    from vstab_amd import apply_pipeline as ap
+
+    out, out_size = ap._expand_matrices(list(s64), (3840, 2160))
+    assert out_size == size and np.array_equal(np.stack(out), np.stack([sh @ m for m in s64]))
     for mode in ("translation", "similarity", "perspective"):
         per_item = np.stack([hm._matrix_to_params(m, mode) for m in stack])
         batch = hm.matrices_to_params(stack, mode)
